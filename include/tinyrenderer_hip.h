@@ -1,0 +1,154 @@
+/*
+ * tinyrenderer_hip.h -- C ABI of the MI355X (gfx950) rasterizer that stands
+ * behind Davidster/tinyrenderer's `model_renderer` draw path.
+ *
+ * The reference has no FFI of its own: its boundary is the Rust function
+ * `render_mesh_component(&mut ModelRendererState, &Object, &mut dyn Fn(VertexShaderArgs)->..,
+ * &mut dyn Fn(FragmentShaderArgs)->..)` (src/model_renderer/mod.rs:225-230) plus
+ * `ModelRendererState::new` (:151), `clear_screen` (:210) and the public
+ * `frame_buffer` / `z_buffer` fields (:30-32).  Host closures cannot run on a
+ * GPU, so the two closures are replaced by a descriptor of the reference's only
+ * shader pair (src/main.rs:146-267).  Every entry point below names the
+ * reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every call returns 0 on success
+ * or a negative TR_ERR_* code and never throws/aborts across the ABI;
+ * `tr_last_error` gives text for the last failure on that context.  One
+ * context per GPU per thread of use (not thread-safe).  The caller keeps
+ * ownership of all host pointers; the library copies.  All matrices are
+ * column-major f64 (nalgebra's storage order).
+ */
+#ifndef TINYRENDERER_HIP_H
+#define TINYRENDERER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tr_context tr_context;
+typedef struct tr_mesh tr_mesh;
+typedef struct tr_texture tr_texture;
+
+enum {
+    TR_OK = 0,
+    TR_ERR_INVALID = -1,      /* bad argument */
+    TR_ERR_HIP = -2,          /* a HIP runtime call failed */
+    TR_ERR_NO_DEVICE = -3,    /* no usable GPU / kernels not loadable */
+    TR_ERR_OOM = -4,
+    TR_ERR_UNSUPPORTED = -5,  /* scene hit a documented limit, see tr_get_status_flags */
+    TR_ERR_SIZE = -6          /* size beyond a documented maximum */
+};
+
+/* Bits of tr_get_status_flags(): conditions met on the device since tr_clear. */
+enum {
+    TR_FLAG_TRI_TOO_LARGE = 1u << 0, /* a triangle's sample grid exceeds 131070 scanlines: skipped
+                                        (the reference has no clipping and would loop ~forever) */
+    TR_FLAG_REF_PANIC_SPLIT = 1u << 1, /* split parameter outside [0,1]: the reference panics
+                                          (model_renderer/mod.rs:441); triangle skipped */
+    TR_FLAG_TEX_OOB = 1u << 2,       /* texture index out of range: the reference panics
+                                        (helpers/mod.rs:262); index clamped */
+    TR_FLAG_NEG_INF_DEPTH = 1u << 3, /* a sample with dist == -inf (reference re-opens the pixel;
+                                        not reproduced) */
+    TR_FLAG_SCANLINE_OVERFLOW = 1u << 4, /* more than 2^32-1 scanlines in one frame */
+    TR_FLAG_NAN_PIXEL_OVERFLOW = 1u << 5 /* more NaN-depth pixels than the side table holds */
+};
+
+/* Buffer layouts for the tr_read_* calls. */
+enum {
+    TR_LAYOUT_ROW_MAJOR = 0, /* element (x,y) at y*W + x        (this library's HBM layout)      */
+    TR_LAYOUT_REFERENCE = 1  /* element (x,y) at x*H + y        (ndarray Array3 (W,H,C) layout,
+                                src/helpers/mod.rs:391-427)                                     */
+};
+
+/* Replaces ModelRendererState::new(w,h), src/model_renderer/mod.rs:151-172.
+ * Allocates the depth / winner / colour planes on `device` and clears them. */
+int tr_create(int device, int width, int height, tr_context** out_ctx);
+void tr_destroy(tr_context* ctx);
+const char* tr_last_error(const tr_context* ctx);
+
+/* Replaces clear_screen, src/model_renderer/mod.rs:210-219: colour (0,0,0,255),
+ * z = -inf, no winner; also forgets the draws recorded since the last clear. */
+int tr_clear(tr_context* ctx);
+
+/* Replaces the wavefront_obj::obj::Object consumed at src/model_renderer/mod.rs:237-276
+ * (geometry[0], Primitive::Triangle only).  idx holds, per triangle, 3 corners x
+ * (vertex, texture, normal) 0-based indices; 0xFFFFFFFF = None (texture / normal only). */
+int tr_mesh_create(tr_context* ctx, const double* positions, int64_t n_positions,
+                   const double* normals, int64_t n_normals, const double* uvw, int64_t n_uvw,
+                   const uint32_t* idx, int64_t n_triangles, tr_mesh** out_mesh);
+int tr_mesh_destroy(tr_context* ctx, tr_mesh* mesh);
+
+/* Replaces MyRgbaImage after flip_vertically (src/model_renderer/mod.rs:40-41,
+ * src/helpers/mod.rs:161-173,291-302): rgba8 is row-major, 4 bytes per texel, and ALREADY
+ * flipped, i.e. row 0 is the bottom row of the decoded image (texel (x,y) = nd_img[[x,y,:]]). */
+int tr_texture_create(tr_context* ctx, const uint8_t* rgba8, int width, int height,
+                      tr_texture** out_tex);
+int tr_texture_destroy(tr_context* ctx, tr_texture* tex);
+
+/* The reference's shader pair (src/main.rs:146-267) as data. */
+typedef struct tr_draw_params {
+    double pmv[16];        /* perspective * model_view, src/main.rs:152-153                  */
+    double normal_mat[16]; /* (model_view^T)^-1, src/main.rs:129-135,164                      */
+    double light_dir[3];   /* camera_pos of src/main.rs:62-64; normalised by the shader :249  */
+    double ambient;        /* src/main.rs:255 (1.0)                                           */
+    double intensity;      /* src/main.rs:254 (1.0)                                           */
+    double vertex_color[4];/* src/main.rs:170 (WHITE = 255,255,255,255)                       */
+    int32_t use_normal_map;/* src/main.rs:182 (true)                                          */
+    int32_t reserved;
+    const tr_texture* diffuse;    /* mesh_component.texture,    src/main.rs:141 */
+    const tr_texture* normal_map; /* mesh_component.normal_map, src/main.rs:140 */
+} tr_draw_params;
+
+/* Replaces render_mesh_component(state, mesh, VS, FS), src/model_renderer/mod.rs:225-475,
+ * for the shader pair above: vertex transform, triangle setup, depth pass.  Winner selection and
+ * shading are deferred to tr_resolve (the reference shades eagerly; the result is the same
+ * because colour = shade(first sample in draw order whose depth equals the final minimum)). */
+int tr_draw(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params);
+
+/* No reference analogue (the reference shades inside the z-test): selects the winning sample per
+ * pixel over all draws since tr_clear and runs the deferred shade.  out_mask selects which
+ * planes are written besides RGBA8 (TR_OUT_*). */
+enum { TR_OUT_RGBA8 = 1, TR_OUT_Z = 2, TR_OUT_TRI_ID = 4, TR_OUT_RGBA_F64 = 8 };
+int tr_resolve(tr_context* ctx, uint32_t out_mask);
+
+/* Replace reads of state.z_buffer.nd_img / state.frame_buffer.nd_img
+ * (src/model_renderer/mod.rs:30-32) and ndarray_to_image_rgba_and_flip
+ * (src/helpers/mod.rs:204-222).  All synchronise the context's stream.
+ *   z:        f64 per pixel, -inf where nothing was drawn.
+ *   tri id:   u32 per pixel = index of the winning triangle counted over all draws since
+ *             tr_clear (draw order, then mesh order); 0xFFFFFFFF where nothing was drawn.
+ *   key:      u64 per pixel = tri_seq<<36 | half<<35 | scanline i<<18 | sample j; ~0 = none.
+ *   rgba8:    `val as u8` of the f64 colour; flip != 0 writes row H-1-y (the presented image).
+ *   rgba f64: 4 f64 per pixel. */
+int tr_read_z_f64(tr_context* ctx, double* out, int layout);
+int tr_read_triangle_id_u32(tr_context* ctx, uint32_t* out, int layout);
+int tr_read_winner_key_u64(tr_context* ctx, uint64_t* out, int layout);
+int tr_read_rgba8(tr_context* ctx, uint8_t* out, int flip);
+int tr_read_rgba_f64(tr_context* ctx, double* out, int layout);
+
+/* Counters since tr_clear: [0] samples enumerated, [1] in-bounds z-tested samples
+ * ("fragments", src/model_renderer/mod.rs:380-389), [2] scanlines, [3] triangles submitted,
+ * [4] pixels with a winner (valid after tr_resolve), [5..7] reserved. */
+int tr_get_counters(tr_context* ctx, uint64_t out[8]);
+int tr_get_status_flags(tr_context* ctx, uint32_t* out_flags);
+
+/* Plumbing for callers that keep data on the GPU (no reference analogue). */
+int tr_synchronize(tr_context* ctx);
+int tr_get_stream(tr_context* ctx, void** out_hip_stream);
+int tr_device_ptr_rgba8(tr_context* ctx, void** out_dev_ptr); /* u32[W*H], row-major */
+/* Per-stage GPU time in ms accumulated since the last call with reset != 0, measured with
+ * hipEvents on the context's stream when profiling is enabled:
+ * [0] clear [1] transform [2] setup+scan [3] depth pass [4] winner pass [5] shade;
+ * counts[i] = number of launches accumulated. */
+int tr_profile_enable(tr_context* ctx, int enable);
+int tr_profile_read(tr_context* ctx, double ms[6], uint64_t counts[6], int reset);
+
+/* Library identity: returns a static string with the build's target arch and ABI version. */
+const char* tr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYRENDERER_HIP_H */

@@ -1,0 +1,658 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle for the tinyrenderer hot path.
+//
+// A single-threaded, sequential C++ restatement of the reference's
+// `render_mesh_component` path (Davidster/tinyrenderer), written to be read
+// side by side with the Rust source.  Every function cites the reference
+// file:line it follows (paths relative to /root/reference/).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this library.  The product (tinyrenderer_amd/) never links, imports or
+// calls it.
+//
+// PARITY PINNING: the reference has no tests, golden vectors or fixtures
+//  and no Rust toolchain exists in the build container,
+// so the Rust binary cannot be run.  This oracle is pinned by (a) the
+// known-answer tests derived by hand from the cited source lines
+// (tests/test_oracle_kat.py) and (b) code review against the citations.
+// Arithmetic that lives inside third-party crates whose source is not in the
+// container (nalgebra 0.30.1 gemv/dot/normalize/try_inverse association) is
+// restated from the crates' published algorithms and is "parity unpinned";
+// each such spot is tagged [nalgebra-unpinned].
+//
+// Build: g++ -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+// All arithmetic is IEEE binary64, one rounding per operation, no FMA.
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- Rust casts
+// Rust `as` casts from f64 saturate and map NaN to 0 (language semantics used
+// at model_renderer/mod.rs:368,377-378; helpers/mod.rs:209,257-258;
+// segment_3d/mod.rs:45).
+inline int64_t rust_as_i64(double v) {
+    if (v != v) return 0;
+    if (v >= 9223372036854775808.0) return INT64_MAX;
+    if (v <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)v;
+}
+inline uint64_t rust_as_usize(double v) {
+    if (v != v) return 0;
+    if (v <= 0.0) return 0;
+    if (v >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+inline uint8_t rust_as_u8(double v) {
+    if (v != v) return 0;
+    if (v <= 0.0) return 0;
+    if (v >= 255.0) return 255;
+    return (uint8_t)v;
+}
+// Rust f64::max / f64::min ignore a NaN operand == C fmax / fmin.
+inline double rmax(double a, double b) { return std::fmax(a, b); }
+inline double rmin(double a, double b) { return std::fmin(a, b); }
+
+// ------------------------------------------------------------ nalgebra types
+struct V3 { double x, y, z; };
+struct V4 { double x, y, z, w; };
+struct M4 { double m[4][4]; };  // m[row][col]
+struct UV { double u, v, w; };  // wavefront_obj::obj::TVertex
+
+// [nalgebra-unpinned] Matrix*Vector goes through gemv: y = col0*x0, then
+// y += col_j*x_j for j=1..  => left-to-right accumulation per row.
+inline V4 mat4_mul_vec4(const M4& a, const V4& v) {
+    double in[4] = {v.x, v.y, v.z, v.w};
+    double out[4];
+    for (int r = 0; r < 4; ++r) {
+        double acc = a.m[r][0] * in[0];
+        for (int j = 1; j < 4; ++j) acc = a.m[r][j] * in[j] + acc;
+        out[r] = acc;
+    }
+    return V4{out[0], out[1], out[2], out[3]};
+}
+// [nalgebra-unpinned] Matrix*Matrix = one gemv per result column.
+inline M4 mat4_mul(const M4& a, const M4& b) {
+    M4 c;
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 4; ++r) {
+            double acc = a.m[r][0] * b.m[0][j];
+            for (int k = 1; k < 4; ++k) acc = a.m[r][k] * b.m[k][j] + acc;
+            c.m[r][j] = acc;
+        }
+    return c;
+}
+// [nalgebra-unpinned] dot of statically sized 3-vectors: a + b + c.
+inline double dot3(const V3& a, const V3& b) {
+    double p0 = a.x * b.x, p1 = a.y * b.y, p2 = a.z * b.z;
+    return (p0 + p1) + p2;
+}
+// [nalgebra-unpinned] dot of statically sized 4-vectors: (a+c) + (b+d).
+inline double dot4(const V4& a, const V4& b) {
+    double p0 = a.x * b.x, p1 = a.y * b.y, p2 = a.z * b.z, p3 = a.w * b.w;
+    p0 += p2;
+    p1 += p3;
+    return p0 + p1;
+}
+// [nalgebra-unpinned] normalize = unscale by sqrt(norm_squared); norm_squared
+// starts from zero and adds the column's self-dot.
+inline V3 normalize3(const V3& a) {
+    double n = std::sqrt(0.0 + dot3(a, a));
+    return V3{a.x / n, a.y / n, a.z / n};
+}
+inline V4 normalize4(const V4& a) {
+    double n = std::sqrt(0.0 + dot4(a, a));
+    return V4{a.x / n, a.y / n, a.z / n, a.w / n};
+}
+inline V3 cross3(const V3& a, const V3& b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// helpers/mod.rs:527-539
+inline M4 make_translation_matrix(V3 t) {
+    return M4{{{1, 0, 0, t.x}, {0, 1, 0, t.y}, {0, 0, 1, t.z}, {0, 0, 0, 1}}};
+}
+inline M4 make_scale_matrix(V3 s) {
+    return M4{{{s.x, 0, 0, 0}, {0, s.y, 0, 0}, {0, 0, s.z, 0}, {0, 0, 0, 1}}};
+}
+
+// ------------------------------------------------------------ image helpers
+// helpers/mod.rs:28, 391-418: MyRgbaImage = Array3<f64> of shape (W,H,4),
+// element [x,y,c] at ((x*H)+y)*4+c.
+struct NdImage {
+    int64_t w = 0, h = 0, c = 0;
+    std::vector<double> d;
+    double& at(int64_t x, int64_t y, int64_t ch) { return d[(size_t)((x * h + y) * c + ch)]; }
+    double at(int64_t x, int64_t y, int64_t ch) const { return d[(size_t)((x * h + y) * c + ch)]; }
+};
+
+// helpers/mod.rs:318-334
+inline void barycentric(const V4& p1, const V4& p2, const V4& p3, const V3& point, double& l1,
+                        double& l2, double& l3) {
+    double det_t = ((p2.y - p3.y) * (p1.x - p3.x)) + ((p3.x - p2.x) * (p1.y - p3.y));
+    l1 = (((p2.y - p3.y) * (point.x - p3.x)) + ((p3.x - p2.x) * (point.y - p3.y))) / det_t;
+    l2 = (((p3.y - p1.y) * (point.x - p3.x)) + ((p1.x - p3.x) * (point.y - p3.y))) / det_t;
+    l3 = 1.0 - l1 - l2;
+}
+
+// helpers/mod.rs:253-278.  Returns false where the reference would panic on an
+// out-of-bounds ndarray index.
+inline bool sample_nd_img(const NdImage& img, double x, double y, double out[4]) {
+    double x1 = std::floor(x);
+    double y1 = std::floor(y);
+    uint64_t ix1 = rust_as_usize(x1), iy1 = rust_as_usize(y1);
+    // (x1 as usize + 1) overflows only for absurd inputs; saturate like a
+    // debug-free wrapping add would not matter because the index check fails.
+    uint64_t ix2u = ix1 == UINT64_MAX ? UINT64_MAX : ix1 + 1;
+    uint64_t iy2u = iy1 == UINT64_MAX ? UINT64_MAX : iy1 + 1;
+    if (ix2u > (uint64_t)(img.w - 1)) ix2u = (uint64_t)(img.w - 1);
+    if (iy2u > (uint64_t)(img.h - 1)) iy2u = (uint64_t)(img.h - 1);
+    double x2 = (double)ix2u;
+    double y2 = (double)iy2u;
+    if (ix1 >= (uint64_t)img.w || iy1 >= (uint64_t)img.h) return false;  // index panic
+    for (int ch = 0; ch < 4; ++ch) {
+        double c0 = img.at((int64_t)ix1, (int64_t)iy1, ch);
+        double c1 = img.at((int64_t)ix2u, (int64_t)iy1, ch);
+        double c2 = img.at((int64_t)ix1, (int64_t)iy2u, ch);
+        double c3 = img.at((int64_t)ix2u, (int64_t)iy2u, ch);
+        out[ch] = c0 * ((x2 - x) * (y2 - y)) + c1 * ((x - x1) * (y2 - y)) +
+                  c2 * ((x2 - x) * (y - y1)) + c3 * ((x - x1) * (y - y1));
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ Segment3D
+// segment_3d/mod.rs:9-116
+struct Segment3D {
+    V3 p1, p2;
+    // :19-36 ; ok=false where the reference returns Err.
+    V3 get_point(double t, bool& ok) const {
+        if (t < 0.0 || t > 1.0) {
+            ok = false;
+            return V3{0, 0, 0};
+        }
+        double d_x = p2.x - p1.x;
+        double d_y = p2.y - p1.y;
+        double d_z = p2.z - p1.z;
+        return V3{p1.x + t * d_x, p1.y + t * d_y, p1.z + t * d_z};
+    }
+    // :41-48
+    int64_t default_resolution() const {
+        int64_t r = rust_as_i64(std::ceil(rmax(std::fabs(p2.x - p1.x), std::fabs(p2.y - p1.y)))) ;
+        // `+ 1` on a saturated i64 would overflow-panic in debug / wrap in
+        // release; unreachable for finite on-screen geometry.
+        if (r != INT64_MAX) r += 1;
+        return r < 2 ? 2 : r;
+    }
+};
+inline V3 xyz(const V4& v) { return V3{v.x, v.y, v.z}; }
+
+}  // namespace
+
+// =========================================================================
+// C API (ctypes)
+// =========================================================================
+extern "C" {
+
+struct OraImage {
+    NdImage img;
+};
+
+// helpers/mod.rs:161-173 image_to_ndarray_rgba: rgba is the decoded image,
+// row-major, row 0 = top (image crate order), 4 bytes per pixel.
+OraImage* ora_image_from_rgba8(const uint8_t* rgba, int64_t w, int64_t h) {
+    OraImage* o = new OraImage();
+    o->img.w = w;
+    o->img.h = h;
+    o->img.c = 4;
+    o->img.d.assign((size_t)(w * h * 4), 0.0);
+    for (int64_t x = 0; x < w; ++x)
+        for (int64_t y = 0; y < h; ++y)
+            for (int ch = 0; ch < 4; ++ch) o->img.at(x, y, ch) = (double)rgba[(y * w + x) * 4 + ch];
+    return o;
+}
+// helpers/mod.rs:291-302
+OraImage* ora_image_flip_vertically(const OraImage* in) {
+    OraImage* o = new OraImage();
+    o->img = in->img;
+    for (int64_t x = 0; x < in->img.w; ++x)
+        for (int64_t y = 0; y < in->img.h; ++y)
+            for (int64_t ch = 0; ch < in->img.c; ++ch)
+                o->img.at(x, y, ch) = in->img.at(x, in->img.h - 1 - y, ch);
+    return o;
+}
+void ora_image_free(OraImage* p) { delete p; }
+int64_t ora_image_width(const OraImage* p) { return p->img.w; }
+int64_t ora_image_height(const OraImage* p) { return p->img.h; }
+const double* ora_image_data(const OraImage* p) { return p->img.d.data(); }
+// helpers/mod.rs:253-278 exposed for known-answer tests; returns 0 on success,
+// 1 where the reference would panic.
+int ora_sample_nd_img(const OraImage* p, double x, double y, double* out4) {
+    return sample_nd_img(p->img, x, y, out4) ? 0 : 1;
+}
+
+// model_renderer/mod.rs:29-35,150-173
+struct OraState {
+    int64_t w, h;
+    NdImage frame_buffer;  // (W,H,4)
+    NdImage z_buffer;      // (W,H,1)
+    NdImage clear_frame_buffer, clear_z_buffer;
+    // Book-keeping the reference does not have (for parity of triangle-id /
+    // winner buffers); layout [x][y] like the z-buffer.
+    std::vector<int64_t> win_draw, win_tri, win_half, win_i, win_j;
+    int64_t draw_count = 0;
+    // counters
+    int64_t n_samples = 0, n_inbounds = 0, n_zpass = 0, n_scanlines = 0, n_culled = 0;
+    int64_t n_tex_panic = 0, n_point_err = 0;
+};
+
+OraState* ora_state_new(int64_t w, int64_t h) {
+    OraState* s = new OraState();
+    s->w = w;
+    s->h = h;
+    s->frame_buffer.w = w; s->frame_buffer.h = h; s->frame_buffer.c = 4;
+    s->frame_buffer.d.assign((size_t)(w * h * 4), 0.0);
+    s->z_buffer.w = w; s->z_buffer.h = h; s->z_buffer.c = 1;
+    s->z_buffer.d.assign((size_t)(w * h), 0.0);
+    const double BLACK[4] = {0.0, 0.0, 0.0, 255.0};  // helpers/mod.rs:22
+    for (int64_t x = 0; x < w; ++x)
+        for (int64_t y = 0; y < h; ++y) {
+            for (int c = 0; c < 4; ++c) s->frame_buffer.at(x, y, c) = BLACK[c];
+            s->z_buffer.at(x, y, 0) = -std::numeric_limits<double>::infinity();
+        }
+    s->clear_frame_buffer = s->frame_buffer;
+    s->clear_z_buffer = s->z_buffer;
+    s->win_draw.assign((size_t)(w * h), -1);
+    s->win_tri = s->win_draw; s->win_half = s->win_draw; s->win_i = s->win_draw; s->win_j = s->win_draw;
+    return s;
+}
+void ora_state_free(OraState* s) { delete s; }
+
+// model_renderer/mod.rs:210-219
+void ora_clear_screen(OraState* s) {
+    s->frame_buffer.d = s->clear_frame_buffer.d;
+    s->z_buffer.d = s->clear_z_buffer.d;
+    std::fill(s->win_draw.begin(), s->win_draw.end(), -1);
+    std::fill(s->win_tri.begin(), s->win_tri.end(), -1);
+    std::fill(s->win_half.begin(), s->win_half.end(), -1);
+    std::fill(s->win_i.begin(), s->win_i.end(), -1);
+    std::fill(s->win_j.begin(), s->win_j.end(), -1);
+    s->draw_count = 0;
+    s->n_samples = s->n_inbounds = s->n_zpass = s->n_scanlines = s->n_culled = 0;
+    s->n_tex_panic = s->n_point_err = 0;
+}
+
+// Mesh as consumed at model_renderer/mod.rs:237-276.  idx holds, per triangle,
+// 3 corners x (vertex, texture, normal) 0-based indices; 0xFFFFFFFF = None.
+struct OraMesh {
+    const double* positions;  // 3*n_pos
+    const double* normals;    // 3*n_nrm
+    const double* uvw;        // 3*n_uvw
+    const uint32_t* idx;      // 9*n_tris
+    int64_t n_pos, n_nrm, n_uvw, n_tris;
+};
+
+// The two closures of main.rs:146-267 as data.  Matrices are column-major
+// (nalgebra storage order).
+struct OraShader {
+    double perspective[16];
+    double model_view[16];
+    double normal_matrix[16];  // (MV^T)^-1, main.rs:129-135 (host-side, an input)
+    double camera_pos[3];      // main.rs:62-64, used as the light direction :249-251
+    double light_intensity;    // main.rs:254
+    double ambient_light;      // main.rs:255
+    int32_t use_normal_map;    // main.rs:182
+    int32_t _pad;
+    const OraImage* texture;     // already flipped (model_renderer/mod.rs:40)
+    const OraImage* normal_map;  // already flipped (model_renderer/mod.rs:41)
+};
+
+static M4 load_m4(const double* cm) {
+    M4 m;
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) m.m[r][c] = cm[c * 4 + r];
+    return m;
+}
+
+struct VSR {  // model_renderer/mod.rs:556-564 VertexShaderResult
+    V4 clip_space_position;
+    V4 normal;
+    bool has_uv;
+    UV uv;
+    double color[4];
+};
+
+// model_renderer/mod.rs:225-475.  Returns 0, or 1 if the reference would have
+// panicked (unwrap of an Err / out-of-bounds texture index); rendering stops at
+// that point like the panic would.
+int ora_render_mesh_component(OraState* st, const OraMesh* mesh, const OraShader* sh) {
+    const int64_t frame_width = st->w, frame_height = st->h;
+    const M4 perspective_matrix = load_m4(sh->perspective);
+    const M4 model_view_matrix = load_m4(sh->model_view);
+    const M4 inverse_model_view_matrix = load_m4(sh->normal_matrix);
+    const int64_t draw_id = st->draw_count++;
+    const uint32_t NONE = 0xFFFFFFFFu;
+
+    // ---- vertex shader closure, main.rs:146-172
+    auto vertex_shader = [&](const V4& local_position, const V4& local_normal, bool has_uv,
+                             const UV& uv) -> VSR {
+        // `perspective_matrix * model_view_matrix_clone * local_position` is
+        // left-associative: a 4x4 product, then matrix*vector (main.rs:152-153).
+        V4 g = mat4_mul_vec4(mat4_mul(perspective_matrix, model_view_matrix), local_position);
+        VSR r;
+        r.clip_space_position = V4{g.x / g.w, g.y / g.w, g.z / g.w, 1.0};
+        r.normal = mat4_mul_vec4(inverse_model_view_matrix, local_normal);
+        r.has_uv = has_uv;
+        r.uv = uv;
+        const double WHITE[4] = {255.0, 255.0, 255.0, 255.0};  // helpers/mod.rs:26
+        for (int c = 0; c < 4; ++c) r.color[c] = WHITE[c];
+        return r;
+    };
+
+    // ---- run_vertex_shader, model_renderer/mod.rs:238-284
+    struct Tri { VSR v[3]; };
+    std::vector<Tri> vertex_shader_results;
+    vertex_shader_results.reserve((size_t)mesh->n_tris);
+    for (int64_t k = 0; k < mesh->n_tris; ++k) {
+        const uint32_t* ix = mesh->idx + 9 * k;
+        auto vtx = [&](int c) {
+            const double* p = mesh->positions + 3 * (size_t)ix[3 * c + 0];
+            return V3{p[0], p[1], p[2]};
+        };
+        V3 v1 = vtx(0), v2 = vtx(1), v3 = vtx(2);
+        auto get_face_normal = [&]() {  // :245-252
+            V3 side_1 = normalize3(V3{v2.x - v1.x, v2.y - v1.y, v2.z - v1.z});
+            V3 side_2 = normalize3(V3{v3.x - v2.x, v3.y - v2.y, v3.z - v2.z});
+            V3 fn = normalize3(cross3(side_1, side_2));
+            return V4{fn.x, fn.y, fn.z, 0.0};
+        };
+        Tri t;
+        for (int c = 0; c < 3; ++c) {
+            uint32_t ni = ix[3 * c + 2], ti = ix[3 * c + 1];
+            V4 n;
+            if (ni != NONE) {
+                const double* p = mesh->normals + 3 * (size_t)ni;
+                n = V4{p[0], p[1], p[2], 0.0};
+            } else {
+                n = get_face_normal();
+            }
+            UV uv{0, 0, 0};
+            bool has_uv = ti != NONE;
+            if (has_uv) {
+                const double* p = mesh->uvw + 3 * (size_t)ti;
+                uv = UV{p[0], p[1], p[2]};
+            }
+            V3 v = c == 0 ? v1 : (c == 1 ? v2 : v3);
+            t.v[c] = vertex_shader(V4{v.x, v.y, v.z, 1.0}, n, has_uv, uv);  // :584-604
+        }
+        vertex_shader_results.push_back(t);
+    }
+
+    // ---- fragment shader closure, main.rs:173-267
+    int status = 0;
+    auto fragment_shader = [&](bool has_tbt, const V4& t_vector, const V4& bt_vector,
+                               const V3& normal_interp, bool has_uv, const UV& uv_interp,
+                               const double color_interp[4], double out_color[4]) -> bool {
+        V3 normal_vector = normal_interp;
+        if (has_uv && has_tbt && sh->use_normal_map) {  // :183-216
+            const NdImage& nm = sh->normal_map->img;
+            double rgb[4];
+            if (!sample_nd_img(nm, uv_interp.u * (double)(nm.w - 1), uv_interp.v * (double)(nm.h - 1), rgb)) {
+                st->n_tex_panic++;
+                status = 1;
+                return false;
+            }
+            auto fix_rgb_range = [](double v) { return ((v / 255.0) * 2.0) - 1.0; };
+            V3 nmn{fix_rgb_range(rgb[0]), fix_rgb_range(rgb[1]), fix_rgb_range(rgb[2])};
+            // Matrix3::new is row-major: rows (t.x bt.x n.x), (t.y bt.y n.y), (t.z bt.z n.z)
+            // [nalgebra-unpinned] 3x3 * vec3 via gemv: left-to-right per row.
+            V3 r;
+            r.x = (t_vector.x * nmn.x + bt_vector.x * nmn.y) + normal_interp.x * nmn.z;
+            r.y = (t_vector.y * nmn.x + bt_vector.y * nmn.y) + normal_interp.y * nmn.z;
+            r.z = (t_vector.z * nmn.x + bt_vector.z * nmn.y) + normal_interp.z * nmn.z;
+            normal_vector = normalize3(r);
+        }
+        double albedo[4];
+        if (has_uv) {  // :221-242
+            const NdImage& tx = sh->texture->img;
+            if (!sample_nd_img(tx, uv_interp.u * (double)(tx.w - 1), uv_interp.v * (double)(tx.h - 1), albedo)) {
+                st->n_tex_panic++;
+                status = 1;
+                return false;
+            }
+        } else {  // :243-244 (color_interp is always Some: VS sets WHITE)
+            for (int c = 0; c < 4; ++c) albedo[c] = color_interp[c];
+        }
+        // :248-265
+        V3 to_light_vec = normalize3(V3{sh->camera_pos[0], sh->camera_pos[1], sh->camera_pos[2]});
+        double diffuse_proportion = rmax(dot3(normal_vector, to_light_vec), 0.0);
+        double light_intensity = sh->light_intensity;
+        double ambient_light = sh->ambient_light;
+        for (int c = 0; c < 3; ++c)
+            out_color[c] = rmin(ambient_light + (diffuse_proportion * light_intensity * albedo[c]), 255.0);
+        out_color[3] = 255.0;
+        return true;
+    };
+
+    // ---- run_fragment_shader per triangle, model_renderer/mod.rs:287-455
+    for (size_t k = 0; k < vertex_shader_results.size() && status == 0; ++k) {
+        const VSR& vsr1 = vertex_shader_results[k].v[0];
+        const VSR& vsr2 = vertex_shader_results[k].v[1];
+        const VSR& vsr3 = vertex_shader_results[k].v[2];
+        auto should_cull_point = [](const V4& p) {  // :293-300
+            return p.x < -1.0 || p.x > 1.0 || p.y < -1.0 || p.y > 1.0 || p.z < -1.0 || p.z > 1.0;
+        };
+        V4 points[3] = {vsr1.clip_space_position, vsr2.clip_space_position, vsr3.clip_space_position};
+        if (should_cull_point(points[0]) && should_cull_point(points[1]) && should_cull_point(points[2])) {
+            st->n_culled++;
+            continue;  // :309-312
+        }
+        // :314-318
+        M4 viewport_matrix = mat4_mul(
+            make_scale_matrix(V3{(double)(frame_width - 1) / 2.0, (double)(frame_height - 1) / 2.0, 1.0}),
+            make_translation_matrix(V3{1.0, 1.0, 0.0}));
+        // :320-327
+        V4 viewport_points[3];
+        for (int c = 0; c < 3; ++c) {
+            V4 p = mat4_mul_vec4(viewport_matrix, V4{points[c].x, points[c].y, points[c].z, 1.0});
+            viewport_points[c] = V4{p.x / p.w, p.y / p.w, p.z / p.w, 1.0};
+        }
+        V4 viewport_points_unsorted[3] = {viewport_points[0], viewport_points[1], viewport_points[2]};
+        // :331 stable sort, comparator b.y.partial_cmp(a.y) (NaN -> Equal): is_less(a,b) <=> b.y < a.y.
+        // Written as the insertion sort std's merge_sort uses for short slices.
+        {
+            auto is_less = [](const V4& a, const V4& b) { return b.y < a.y; };
+            for (int i = 1; i >= 0; --i) {  // insert_head(v[i..])
+                if (is_less(viewport_points[i + 1], viewport_points[i])) {
+                    V4 tmp = viewport_points[i];
+                    viewport_points[i] = viewport_points[i + 1];
+                    int dest = i + 1;
+                    for (int j = i + 2; j < 3; ++j) {
+                        if (!is_less(viewport_points[j], tmp)) break;
+                        viewport_points[j - 1] = viewport_points[j];
+                        dest = j;
+                    }
+                    viewport_points[dest] = tmp;
+                }
+            }
+        }
+        // :333-358 tangent / bitangent
+        bool has_tbt = false;
+        V4 t_vector{0, 0, 0, 0}, bt_vector{0, 0, 0, 0};
+        if (vsr1.has_uv && vsr2.has_uv && vsr3.has_uv) {
+            const UV &uv1 = vsr1.uv, &uv2 = vsr2.uv, &uv3 = vsr3.uv;
+            double m11 = uv2.u - uv1.u, m12 = uv2.v - uv1.v;
+            double m21 = uv3.u - uv1.u, m22 = uv3.v - uv1.v;
+            double e[2][3] = {
+                {points[1].x - points[0].x, points[1].y - points[0].y, points[1].z - points[0].z},
+                {points[2].x - points[0].x, points[2].y - points[0].y, points[2].z - points[0].z}};
+            // [nalgebra-unpinned] 2x2 try_inverse: det = m11*m22 - m21*m12; None iff det == 0.
+            double determinant = m11 * m22 - m21 * m12;
+            if (determinant != 0.0) {
+                double i11 = m22 / determinant, i12 = -m12 / determinant;
+                double i21 = -m21 / determinant, i22 = m11 / determinant;
+                // [nalgebra-unpinned] (2x2)*(2x3) via gemv per column.
+                double tb[2][3];
+                for (int c = 0; c < 3; ++c) {
+                    tb[0][c] = i12 * e[1][c] + i11 * e[0][c];
+                    tb[1][c] = i22 * e[1][c] + i21 * e[0][c];
+                }
+                t_vector = normalize4(V4{tb[0][0], tb[0][1], tb[0][2], 0.0});
+                bt_vector = normalize4(V4{tb[1][0], tb[1][1], tb[1][2], 0.0});
+                has_tbt = true;
+            }
+        }
+
+        // :360-433
+        auto fill_half_triangle = [&](const Segment3D& segment_a, const Segment3D& segment_b,
+                                      int64_t half) -> bool {
+            int64_t resolution = rust_as_i64(std::ceil(
+                rmax(rmax(rmax(std::fabs(segment_a.p2.x - segment_a.p1.x),
+                               std::fabs(segment_a.p2.y - segment_a.p1.y)),
+                          std::fabs(segment_b.p2.x - segment_a.p1.x)),
+                     std::fabs(segment_b.p2.y - segment_a.p1.y))));
+            if (resolution < 2) resolution = 2;
+            // zip of two SegmentRange iterators (segment_3d/mod.rs:103-115)
+            for (int64_t i = 0; i <= resolution; ++i) {
+                double delta = 1.0 / (double)resolution;
+                bool ok = true;
+                V3 segment_a_point = segment_a.get_point((double)i * delta, ok);
+                V3 segment_b_point = segment_b.get_point((double)i * delta, ok);
+                if (!ok) { st->n_point_err++; return false; }  // unwrap panic :111
+                st->n_scanlines++;
+                Segment3D horizontal_segment{segment_a_point, segment_b_point};  // :374
+                int64_t hres = horizontal_segment.default_resolution();         // :375
+                for (int64_t j = 0; j <= hres; ++j) {
+                    double hdelta = 1.0 / (double)hres;
+                    V3 p = horizontal_segment.get_point((double)j * hdelta, ok);
+                    if (!ok) { st->n_point_err++; return false; }
+                    st->n_samples++;
+                    int64_t x = rust_as_i64(std::round(p.x));  // :377
+                    int64_t y = rust_as_i64(std::round(p.y));  // :378
+                    double dist = -p.z;                        // :379
+                    if (x < 0 || x > frame_width - 1 || y < 0 || y > frame_height - 1) continue;  // :380-386
+                    st->n_inbounds++;
+                    double current_z = st->z_buffer.at(x, y, 0);  // :388
+                    if (current_z == -std::numeric_limits<double>::infinity() || current_z > dist) {  // :389
+                        st->z_buffer.at(x, y, 0) = dist;  // :390
+                        st->n_zpass++;
+                        size_t pix = (size_t)(x * frame_height + y);
+                        st->win_draw[pix] = draw_id; st->win_tri[pix] = (int64_t)k;
+                        st->win_half[pix] = half; st->win_i[pix] = i; st->win_j[pix] = j;
+                        // get_fragment_shader_elements :477-535
+                        double l1, l2, l3;
+                        barycentric(viewport_points_unsorted[0], viewport_points_unsorted[1],
+                                    viewport_points_unsorted[2], p, l1, l2, l3);
+                        const V4 &n1 = vsr1.normal, &n2 = vsr2.normal, &n3 = vsr3.normal;
+                        V3 normal_interp = normalize3(V3{l1 * n1.x + l2 * n2.x + l3 * n3.x,
+                                                         l1 * n1.y + l2 * n2.y + l3 * n3.y,
+                                                         l1 * n1.z + l2 * n2.z + l3 * n3.z});
+                        bool has_uv = vsr1.has_uv && vsr2.has_uv && vsr3.has_uv;
+                        UV uvi{0, 0, 0};
+                        if (has_uv) {
+                            uvi.u = l1 * vsr1.uv.u + l2 * vsr2.uv.u + l3 * vsr3.uv.u;
+                            uvi.v = l1 * vsr1.uv.v + l2 * vsr2.uv.v + l3 * vsr3.uv.v;
+                            uvi.w = l1 * vsr1.uv.w + l2 * vsr2.uv.w + l3 * vsr3.uv.w;
+                        }
+                        double color_interp[4];
+                        for (int c = 0; c < 4; ++c)
+                            color_interp[c] = l1 * vsr1.color[c] + l2 * vsr2.color[c] + l3 * vsr3.color[c];
+                        double color[4];
+                        if (!fragment_shader(has_tbt, t_vector, bt_vector, normal_interp, has_uv, uvi,
+                                             color_interp, color))
+                            return false;
+                        for (int c = 0; c < 4; ++c) st->frame_buffer.at(x, y, c) = color[c];  // :414-416
+                    }
+                }
+            }
+            return true;
+        };
+
+        // :435-441
+        Segment3D long_side_segment{xyz(viewport_points[0]), xyz(viewport_points[2])};
+        bool ok = true;
+        V3 long_side_split_point = long_side_segment.get_point(
+            (viewport_points[1].y - viewport_points[0].y) / (viewport_points[2].y - viewport_points[0].y), ok);
+        if (!ok) { st->n_point_err++; status = 1; break; }  // .unwrap() panic
+        // :443-452
+        if (!fill_half_triangle(Segment3D{xyz(viewport_points[0]), xyz(viewport_points[1])},
+                                Segment3D{xyz(viewport_points[0]), long_side_split_point}, 0)) {
+            status = 1;
+            break;
+        }
+        if (!fill_half_triangle(Segment3D{xyz(viewport_points[2]), xyz(viewport_points[1])},
+                                Segment3D{xyz(viewport_points[2]), long_side_split_point}, 1)) {
+            status = 1;
+            break;
+        }
+    }
+    return status;
+}
+
+// Buffers in the reference's own layout: element [x,y,c] at ((x*H)+y)*C+c.
+const double* ora_z_buffer(const OraState* s) { return s->z_buffer.d.data(); }
+const double* ora_frame_buffer(const OraState* s) { return s->frame_buffer.d.data(); }
+const int64_t* ora_win_draw(const OraState* s) { return s->win_draw.data(); }
+const int64_t* ora_win_tri(const OraState* s) { return s->win_tri.data(); }
+const int64_t* ora_win_half(const OraState* s) { return s->win_half.data(); }
+const int64_t* ora_win_i(const OraState* s) { return s->win_i.data(); }
+const int64_t* ora_win_j(const OraState* s) { return s->win_j.data(); }
+// counters: [samples, inbounds, zpass, scanlines, culled, tex_panic, point_err]
+void ora_counters(const OraState* s, int64_t* out7) {
+    out7[0] = s->n_samples; out7[1] = s->n_inbounds; out7[2] = s->n_zpass; out7[3] = s->n_scanlines;
+    out7[4] = s->n_culled; out7[5] = s->n_tex_panic; out7[6] = s->n_point_err;
+}
+
+// helpers/mod.rs:204-222 ndarray_to_image_rgba_and_flip -> row-major RGBA8, row 0 = top.
+void ora_present_rgba8_flip(const OraState* s, uint8_t* out) {
+    for (int64_t x = 0; x < s->w; ++x)
+        for (int64_t y = 0; y < s->h; ++y) {
+            int64_t oy = (s->h - 1) - y;
+            for (int c = 0; c < 4; ++c) out[(oy * s->w + x) * 4 + c] = rust_as_u8(s->frame_buffer.at(x, y, c));
+        }
+}
+
+// ---- small pieces exposed for known-answer tests -------------------------
+// segment_3d/mod.rs:37-115: iterate a segment with default (res<0) or given
+// resolution; writes up to cap points (xyz) and returns the number of points
+// the iterator yields, or -1 on an Err.
+int64_t ora_segment_points(const double p1[3], const double p2[3], int64_t resolution, double* out_xyz,
+                           int64_t cap) {
+    Segment3D s{V3{p1[0], p1[1], p1[2]}, V3{p2[0], p2[1], p2[2]}};
+    int64_t res = resolution < 0 ? s.default_resolution() : resolution;
+    if (res < 2) return -1;
+    int64_t n = 0;
+    for (int64_t i = 0; i <= res; ++i) {
+        double delta = 1.0 / (double)res;
+        bool ok = true;
+        V3 p = s.get_point((double)i * delta, ok);
+        if (!ok) return -1;
+        if (n < cap) { out_xyz[3 * n] = p.x; out_xyz[3 * n + 1] = p.y; out_xyz[3 * n + 2] = p.z; }
+        ++n;
+    }
+    return n;
+}
+void ora_barycentric(const double p1[2], const double p2[2], const double p3[2], const double pt[2], double* out3) {
+    V4 a{p1[0], p1[1], 0, 1}, b{p2[0], p2[1], 0, 1}, c{p3[0], p3[1], 0, 1};
+    barycentric(a, b, c, V3{pt[0], pt[1], 0}, out3[0], out3[1], out3[2]);
+}
+// n*(1/n) <= 1 check used by KAT (2): returns the first n in [lo,hi] violating it, or 0.
+int64_t ora_check_unit_param(int64_t lo, int64_t hi) {
+    for (int64_t n = lo; n <= hi; ++n) {
+        double delta = 1.0 / (double)n;
+        double t = (double)n * delta;
+        if (t < 0.0 || t > 1.0) return n;
+    }
+    return 0;
+}
+void ora_mat4_mul(const double* a_cm, const double* b_cm, double* out_cm) {
+    M4 c = mat4_mul(load_m4(a_cm), load_m4(b_cm));
+    for (int col = 0; col < 4; ++col)
+        for (int r = 0; r < 4; ++r) out_cm[col * 4 + r] = c.m[r][col];
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+"""Shared helpers for parity tests: render one scene through the oracle and through the GPU
+library from the same inputs, and compare every plane."""
+import numpy as np
+
+from tinyrenderer_amd import _ffi, scenes
+from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+_components = {}
+
+
+def component(name):
+    """Cached MeshComponent for 'head', 'eye_inner' or 'diablo'."""
+    if name not in _components:
+        triple = {"head": scenes.AFRICAN_HEAD, "eye_inner": scenes.AFRICAN_HEAD_EYE_INNER,
+                  "diablo": scenes.DIABLO}[name]
+        _components[name] = scenes.load_component(triple)
+    return _components[name]
+
+
+def pack_key(w):
+    """Oracle winner arrays -> the library's u64 key (tri_seq<<36 | half<<35 | i<<18 | j)."""
+    none = w["tri"] < 0
+    key = ((w["seq"].astype(np.uint64) << np.uint64(36)) | (w["half"].astype(np.uint64) << np.uint64(35))
+           | (w["i"].astype(np.uint64) << np.uint64(18)) | w["j"].astype(np.uint64))
+    key[none] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    return key
+
+
+def oracle_render(oracle, W, H, draws):
+    """draws: list of (MeshComponent, BuiltinShader).  Returns dict of planes in (W,H,..) layout."""
+    st = oracle.OracleState(W, H)
+    st.clear_screen()
+    imgs = {}
+    tri_base = []
+    base = 0
+    for mc, sh in draws:
+        for img in (mc.texture, mc.normal_map):
+            if img is not None and id(img) not in imgs:
+                # the oracle flips by itself (model_renderer/mod.rs:40-41): hand it the un-flipped image
+                imgs[id(img)] = oracle.OracleImage(img[::-1], flip=True)
+        rc = st.render_mesh_component(mc.mesh, sh, imgs.get(id(mc.texture)), imgs.get(id(mc.normal_map)))
+        assert rc == 0, "oracle: the reference would have panicked on this scene"
+        tri_base.append(base)
+        base += mc.mesh.triangles.shape[0]
+    w = st.winners()
+    tb = np.array(tri_base + [0], dtype=np.int64)
+    w["seq"] = np.where(w["tri"] >= 0, tb[np.clip(w["draw"], 0, len(tri_base) - 1)] + w["tri"], -1)
+    return {"z": st.z_buffer()[..., 0], "fb": st.frame_buffer(), "key": pack_key(w), "seq": w["seq"],
+            "present": st.present(), "counters": st.counters()}
+
+
+def gpu_render(W, H, draws, device=0):
+    st = ModelRendererState(W, H, device=device)
+    try:
+        clear_screen(st)
+        for mc, sh in draws:
+            render_mesh_component(st, mc, sh)
+        st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z | _ffi.TR_OUT_TRI_ID | _ffi.TR_OUT_RGBA_F64)
+        out = {"z": st.z_buffer[..., 0], "fb": st.frame_buffer, "key": st.winner_keys(),
+               "seq": st.triangle_ids().astype(np.int64), "present": st.present(),
+               "counters": st.counters(), "flags": st.status_flags()}
+        out["seq"][out["seq"] == 0xFFFFFFFF] = -1
+        return out
+    finally:
+        st.close()
+
+
+def assert_parity(o, g, color_lsb=1):
+    """Bit-exact depth / winner / triangle id; colour within `color_lsb` in the presented u8 domain."""
+    assert g["flags"] == 0, f"status flags {g['flags']:#x}"
+    zo, zg = o["z"], g["z"]
+    assert zo.shape == zg.shape
+    same = (zo.view(np.uint64) == zg.view(np.uint64)) | (np.isnan(zo) & np.isnan(zg))
+    assert same.all(), f"{(~same).sum()} depth mismatches, first at {np.argwhere(~same)[:5].tolist()}"
+    assert (o["seq"] == g["seq"]).all(), f"{(o['seq'] != g['seq']).sum()} triangle-id mismatches"
+    assert (o["key"] == g["key"]).all(), f"{(o['key'] != g['key']).sum()} winner-key mismatches"
+    d = np.abs(o["present"].astype(np.int16) - g["present"].astype(np.int16))
+    assert d.max() <= color_lsb, f"presented colour differs by {d.max()} LSB"
+    fo, fg = o["fb"], g["fb"]
+    exact = (fo.view(np.uint64) == fg.view(np.uint64)) | (np.isnan(fo) & np.isnan(fg))
+    return {"max_lsb": int(d.max()), "f64_colour_mismatches": int((~exact).sum()),
+            "covered": int(np.isfinite(zo).sum())}

@@ -1,0 +1,114 @@
+"""ctypes binding of the C-ABI library (include/tinyrenderer_hip.h).
+
+The library is the product; this module only declares its entry points.  There is no
+fallback: if the shared object is missing or no gfx950 GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtinyrenderer_hip.so")
+
+TR_OK = 0
+TR_ERR = {
+    -1: "TR_ERR_INVALID",
+    -2: "TR_ERR_HIP",
+    -3: "TR_ERR_NO_DEVICE",
+    -4: "TR_ERR_OOM",
+    -5: "TR_ERR_UNSUPPORTED",
+    -6: "TR_ERR_SIZE",
+}
+TR_FLAG_TRI_TOO_LARGE = 1 << 0
+TR_FLAG_REF_PANIC_SPLIT = 1 << 1
+TR_FLAG_TEX_OOB = 1 << 2
+TR_FLAG_NEG_INF_DEPTH = 1 << 3
+TR_FLAG_SCANLINE_OVERFLOW = 1 << 4
+TR_FLAG_NAN_PIXEL_OVERFLOW = 1 << 5
+TR_LAYOUT_ROW_MAJOR = 0
+TR_LAYOUT_REFERENCE = 1
+TR_OUT_RGBA8, TR_OUT_Z, TR_OUT_TRI_ID, TR_OUT_RGBA_F64 = 1, 2, 4, 8
+
+# Every symbol include/tinyrenderer_hip.h declares (checked by tests/test_abi.py).
+EXPORTS = [
+    "tr_create", "tr_destroy", "tr_last_error", "tr_clear", "tr_mesh_create", "tr_mesh_destroy",
+    "tr_texture_create", "tr_texture_destroy", "tr_draw", "tr_resolve", "tr_read_z_f64",
+    "tr_read_triangle_id_u32", "tr_read_winner_key_u64", "tr_read_rgba8", "tr_read_rgba_f64",
+    "tr_get_counters", "tr_get_status_flags", "tr_synchronize", "tr_get_stream",
+    "tr_device_ptr_rgba8", "tr_profile_enable", "tr_profile_read", "tr_version",
+]
+
+
+class DrawParams(C.Structure):
+    _fields_ = [
+        ("pmv", C.c_double * 16),
+        ("normal_mat", C.c_double * 16),
+        ("light_dir", C.c_double * 3),
+        ("ambient", C.c_double),
+        ("intensity", C.c_double),
+        ("vertex_color", C.c_double * 4),
+        ("use_normal_map", C.c_int32),
+        ("reserved", C.c_int32),
+        ("diffuse", C.c_void_p),
+        ("normal_map", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (does not touch the GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C tinyrenderer_amd/csrc` "
+            "(or __graft_entry__.build()); there is no CPU fallback"
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint32
+    pd = C.POINTER(C.c_double)
+    sig = {
+        "tr_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
+        "tr_destroy": (None, [vp]),
+        "tr_last_error": (C.c_char_p, [vp]),
+        "tr_clear": (i32, [vp]),
+        "tr_mesh_create": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, i64, C.POINTER(vp)]),
+        "tr_mesh_destroy": (i32, [vp, vp]),
+        "tr_texture_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "tr_texture_destroy": (i32, [vp, vp]),
+        "tr_draw": (i32, [vp, vp, C.POINTER(DrawParams)]),
+        "tr_resolve": (i32, [vp, u32]),
+        "tr_read_z_f64": (i32, [vp, vp, i32]),
+        "tr_read_triangle_id_u32": (i32, [vp, vp, i32]),
+        "tr_read_winner_key_u64": (i32, [vp, vp, i32]),
+        "tr_read_rgba8": (i32, [vp, vp, i32]),
+        "tr_read_rgba_f64": (i32, [vp, vp, i32]),
+        "tr_get_counters": (i32, [vp, C.POINTER(C.c_uint64)]),
+        "tr_get_status_flags": (i32, [vp, C.POINTER(u32)]),
+        "tr_synchronize": (i32, [vp]),
+        "tr_get_stream": (i32, [vp, C.POINTER(vp)]),
+        "tr_device_ptr_rgba8": (i32, [vp, C.POINTER(vp)]),
+        "tr_profile_enable": (i32, [vp, i32]),
+        "tr_profile_read": (i32, [vp, pd, C.POINTER(C.c_uint64), i32]),
+        "tr_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class TrError(RuntimeError):
+    pass
+
+
+def check(ctx, rc, what):
+    if rc != TR_OK:
+        msg = ""
+        if ctx:
+            msg = load().tr_last_error(ctx).decode(errors="replace")
+        raise TrError(f"{what} failed: {TR_ERR.get(rc, rc)} {msg}")

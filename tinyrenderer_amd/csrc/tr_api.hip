@@ -1,0 +1,620 @@
+// C ABI of the gfx950 rasterizer (include/tinyrenderer_hip.h).  Host-side orchestration
+// only: every per-vertex / per-sample / per-pixel operation runs in tr_kernels.hip.
+// There is no CPU fallback: without a usable GPU tr_create fails with TR_ERR_NO_DEVICE.
+#include "../../include/tinyrenderer_hip.h"
+#include "tr_kernels.hip"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace tr;
+
+struct tr_texture {
+    uint32_t* dev = nullptr;
+    int w = 0, h = 0;
+};
+
+struct tr_mesh {
+    double* pos = nullptr;
+    double* nrm = nullptr;
+    double* uvw = nullptr;
+    uint32_t* idx = nullptr;
+    int64_t n_pos = 0, n_nrm = 0, n_uvw = 0, n_tris = 0;
+    bool any_uv = false;
+};
+
+enum { ST_CLEAR = 0, ST_TRANSFORM, ST_SETUP, ST_DEPTH, ST_WINNER, ST_SHADE, ST_COUNT };
+
+struct tr_context {
+    int device = 0;
+    int W = 0, H = 0;
+    int y_lo = 0, y_hi = 0;
+    hipStream_t stream = nullptr;
+    unsigned long long* planes = nullptr;  // depth[W*H] then wkey[W*H]
+    unsigned long long* depth = nullptr;
+    unsigned long long* wkey = nullptr;
+    uint32_t* rgba8 = nullptr;
+    double* z_out = nullptr;
+    uint32_t* tri_out = nullptr;
+    double* rgba_f64 = nullptr;
+    TriRaster* rast = nullptr;
+    TriShade* shade = nullptr;
+    uint32_t* half_cnt = nullptr;
+    uint32_t* half_off = nullptr;
+    size_t tri_cap = 0;
+    unsigned long long* tile_sum = nullptr;
+    size_t tile_cap = 0;
+    double* ndc = nullptr;
+    double* nout = nullptr;
+    size_t ndc_cap = 0, nout_cap = 0;
+    DrawDev* draw_table = nullptr;
+    uint32_t draw_cap = 4096;
+    unsigned long long* counters = nullptr;
+    uint32_t* flags = nullptr;
+    NanTable* nan = nullptr;
+    uint32_t tri_total = 0;
+    uint32_t draw_count = 0;
+    uint32_t resolved_mask = 0;
+    bool resolved = false;
+    std::string err;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double prof_ms[ST_COUNT] = {0};
+    uint64_t prof_n[ST_COUNT] = {0};
+};
+
+namespace {
+
+int fail(tr_context* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define TR_HIP(c, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(c, e_ == hipErrorOutOfMemory ? TR_ERR_OOM : TR_ERR_HIP,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+struct ProfScope {
+    tr_context* c;
+    int stage;
+    ProfScope(tr_context* c_, int s) : c(c_), stage(s) {
+        if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~ProfScope() {
+        if (c->prof) {
+            (void)hipEventRecord(c->ev1, c->stream);
+            (void)hipEventSynchronize(c->ev1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            c->prof_ms[stage] += ms;
+            c->prof_n[stage] += 1;
+        }
+    }
+};
+
+// nalgebra's 4x4 * 4x4 (one gemv per result column, left-to-right accumulation); used for the
+// viewport matrix of src/model_renderer/mod.rs:314-318.
+Mat4 host_mat4_mul(const Mat4& a, const Mat4& b) {
+    Mat4 c;
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 4; ++r) {
+            double acc = a.m[r] * b.m[j * 4];
+            for (int k = 1; k < 4; ++k) acc = a.m[k * 4 + r] * b.m[j * 4 + k] + acc;
+            c.m[j * 4 + r] = acc;
+        }
+    return c;
+}
+
+int ensure_tri_capacity(tr_context* c, size_t need) {
+    if (need <= c->tri_cap) return TR_OK;
+    size_t cap = c->tri_cap ? c->tri_cap : 16384;
+    while (cap < need) cap *= 2;
+    TriRaster* nr = nullptr;
+    TriShade* ns = nullptr;
+    uint32_t *ncnt = nullptr, *noff = nullptr;
+    TR_HIP(c, hipMalloc(&nr, cap * sizeof(TriRaster)));
+    TR_HIP(c, hipMalloc(&ns, cap * sizeof(TriShade)));
+    TR_HIP(c, hipMalloc(&ncnt, 2 * cap * sizeof(uint32_t)));
+    TR_HIP(c, hipMalloc(&noff, (2 * cap + 1) * sizeof(uint32_t)));
+    if (c->tri_total) {  // keep the draws already recorded this frame
+        size_t n = c->tri_total;
+        TR_HIP(c, hipMemcpyAsync(nr, c->rast, n * sizeof(TriRaster), hipMemcpyDeviceToDevice, c->stream));
+        TR_HIP(c, hipMemcpyAsync(ns, c->shade, n * sizeof(TriShade), hipMemcpyDeviceToDevice, c->stream));
+        TR_HIP(c, hipMemcpyAsync(ncnt, c->half_cnt, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        TR_HIP(c, hipMemcpyAsync(noff, c->half_off, (2 * n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    } else if (c->half_off) {
+        TR_HIP(c, hipMemcpyAsync(noff, c->half_off, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        TR_HIP(c, hipMemsetAsync(noff, 0, sizeof(uint32_t), c->stream));
+    }
+    TR_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt); (void)hipFree(c->half_off);
+    c->rast = nr; c->shade = ns; c->half_cnt = ncnt; c->half_off = noff;
+    c->tri_cap = cap;
+    size_t tiles = (2 * cap + kScanTile - 1) / kScanTile;
+    if (tiles > c->tile_cap) {
+        (void)hipFree(c->tile_sum);
+        c->tile_sum = nullptr;
+        TR_HIP(c, hipMalloc(&c->tile_sum, tiles * sizeof(unsigned long long)));
+        c->tile_cap = tiles;
+    }
+    return TR_OK;
+}
+
+int ensure_scratch(tr_context* c, double** p, size_t* cap, size_t need) {
+    if (need <= *cap) return TR_OK;
+    TR_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    TR_HIP(c, hipMalloc(p, need * sizeof(double)));
+    *cap = need;
+    return TR_OK;
+}
+
+constexpr int kRasterBlocks = 8192;
+
+int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi) {
+    RasterArgs ra;
+    ra.half_off = c->half_off;
+    ra.rast = c->rast;
+    ra.depth = c->depth;
+    ra.wkey = c->wkey;
+    ra.h_lo = h_lo;
+    ra.h_hi = h_hi;
+    ra.W = c->W;
+    ra.H = c->H;
+    ra.y_lo = c->y_lo;
+    ra.y_hi = c->y_hi;
+    ra.counters = c->counters;
+    ra.flags = c->flags;
+    ra.nan = c->nan;
+    if (pass == 0)
+        hipLaunchKernelGGL(k_raster<0>, dim3(kRasterBlocks), dim3(64), 0, c->stream, ra);
+    else
+        hipLaunchKernelGGL(k_raster<1>, dim3(kRasterBlocks), dim3(64), 0, c->stream, ra);
+    TR_HIP(c, hipGetLastError());
+    return TR_OK;
+}
+
+int need_plane(tr_context* c, uint32_t plane) {
+    if (c->resolved && (c->resolved_mask & plane)) return TR_OK;
+    return tr_resolve(c, (c->resolved ? c->resolved_mask : 0u) | plane);
+}
+
+template <typename T>
+int read_plane(tr_context* c, const T* dev, T* out, int layout, int comps) {
+    size_t npix = (size_t)c->W * c->H;
+    if (layout == TR_LAYOUT_ROW_MAJOR) {
+        TR_HIP(c, hipMemcpyAsync(out, dev, npix * comps * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        TR_HIP(c, hipStreamSynchronize(c->stream));
+        return TR_OK;
+    }
+    if (layout != TR_LAYOUT_REFERENCE) return fail(c, TR_ERR_INVALID, "unknown layout");
+    std::vector<T> tmp(npix * comps);
+    TR_HIP(c, hipMemcpyAsync(tmp.data(), dev, npix * comps * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    TR_HIP(c, hipStreamSynchronize(c->stream));
+    for (int y = 0; y < c->H; ++y)
+        for (int x = 0; x < c->W; ++x)
+            for (int k = 0; k < comps; ++k)
+                out[((size_t)x * c->H + y) * comps + k] = tmp[((size_t)y * c->W + x) * comps + k];
+    return TR_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+const char* tr_version(void) { return "tinyrenderer_hip abi=1 arch=gfx950 fp=f64 contract=off"; }
+
+const char* tr_last_error(const tr_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int tr_create(int device, int width, int height, tr_context** out_ctx) {
+    if (!out_ctx) return TR_ERR_INVALID;
+    *out_ctx = nullptr;
+    if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return TR_ERR_SIZE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+        return TR_ERR_NO_DEVICE;
+    tr_context* c = new (std::nothrow) tr_context();
+    if (!c) return TR_ERR_OOM;
+    c->device = device;
+    c->W = width;
+    c->H = height;
+    c->y_lo = 0;
+    c->y_hi = height;
+    auto bail = [&](int code) {
+        tr_destroy(c);
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(TR_ERR_NO_DEVICE);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(TR_ERR_NO_DEVICE);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "tinyrenderer_hip: device %d is %s, kernels are built for gfx950 only\n",
+                     device, prop.gcnArchName);
+        return bail(TR_ERR_NO_DEVICE);
+    }
+    size_t npix = (size_t)width * height;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMalloc(&c->planes, 2 * npix * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
+    c->depth = c->planes;
+    c->wkey = c->planes + npix;
+    if (hipMalloc(&c->rgba8, npix * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->draw_table, c->draw_cap * sizeof(DrawDev)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->counters, 8 * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->flags, sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->nan, sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(TR_ERR_HIP);
+    if (ensure_tri_capacity(c, 16384) != TR_OK) return bail(TR_ERR_OOM);
+    int rc = tr_clear(c);
+    if (rc != TR_OK) return bail(rc);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    *out_ctx = c;
+    return TR_OK;
+}
+
+void tr_destroy(tr_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
+    (void)hipFree(c->rgba_f64); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
+    (void)hipFree(c->half_off); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
+    (void)hipFree(c->draw_table); (void)hipFree(c->counters); (void)hipFree(c->flags); (void)hipFree(c->nan);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int tr_clear(tr_context* c) {
+    if (!c) return TR_ERR_INVALID;
+    TR_HIP(c, hipSetDevice(c->device));
+    ProfScope ps(c, ST_CLEAR);
+    size_t npix = (size_t)c->W * c->H;
+    // depth = "no sample yet", winner = none: both all-ones.
+    TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * npix * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_reset_frame, dim3(1), dim3(64), 0, c->stream, c->counters, c->flags, c->nan, c->half_off);
+    TR_HIP(c, hipGetLastError());
+    c->tri_total = 0;
+    c->draw_count = 0;
+    c->resolved = false;
+    c->resolved_mask = 0;
+    return TR_OK;
+}
+
+int tr_mesh_create(tr_context* c, const double* positions, int64_t n_positions, const double* normals,
+                   int64_t n_normals, const double* uvw, int64_t n_uvw, const uint32_t* idx,
+                   int64_t n_triangles, tr_mesh** out_mesh) {
+    if (!c || !out_mesh) return TR_ERR_INVALID;
+    *out_mesh = nullptr;
+    if (n_positions < 0 || n_normals < 0 || n_uvw < 0 || n_triangles < 0)
+        return fail(c, TR_ERR_INVALID, "negative count");
+    if (n_triangles > (int64_t)kTriSeqMax || n_positions > (int64_t)1 << 30 || n_normals > (int64_t)1 << 30 ||
+        n_uvw > (int64_t)1 << 30)
+        return fail(c, TR_ERR_SIZE, "mesh too large");
+    if ((n_positions && !positions) || (n_normals && !normals) || (n_uvw && !uvw) || (n_triangles && !idx))
+        return fail(c, TR_ERR_INVALID, "null array");
+    bool any_uv = false;
+    for (int64_t k = 0; k < n_triangles; ++k)
+        for (int cnr = 0; cnr < 3; ++cnr) {
+            uint32_t v = idx[9 * k + 3 * cnr], t = idx[9 * k + 3 * cnr + 1], n = idx[9 * k + 3 * cnr + 2];
+            if ((int64_t)v >= n_positions) return fail(c, TR_ERR_INVALID, "vertex index out of range");
+            if (t != 0xFFFFFFFFu && (int64_t)t >= n_uvw) return fail(c, TR_ERR_INVALID, "texture index out of range");
+            if (n != 0xFFFFFFFFu && (int64_t)n >= n_normals) return fail(c, TR_ERR_INVALID, "normal index out of range");
+            any_uv = any_uv || t != 0xFFFFFFFFu;
+        }
+    TR_HIP(c, hipSetDevice(c->device));
+    tr_mesh* m = new (std::nothrow) tr_mesh();
+    if (!m) return fail(c, TR_ERR_OOM, "host allocation failed");
+    m->n_pos = n_positions; m->n_nrm = n_normals; m->n_uvw = n_uvw; m->n_tris = n_triangles;
+    m->any_uv = any_uv;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        size_t alloc = bytes ? bytes : 8;
+        hipError_t e = hipMalloc(dst, alloc);
+        if (e != hipSuccess) return e;
+        if (bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    hipError_t e = up((void**)&m->pos, positions, (size_t)n_positions * 3 * sizeof(double));
+    if (e == hipSuccess) e = up((void**)&m->nrm, normals, (size_t)n_normals * 3 * sizeof(double));
+    if (e == hipSuccess) e = up((void**)&m->uvw, uvw, (size_t)n_uvw * 3 * sizeof(double));
+    if (e == hipSuccess) e = up((void**)&m->idx, idx, (size_t)n_triangles * 9 * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        tr_mesh_destroy(c, m);
+        return fail(c, e == hipErrorOutOfMemory ? TR_ERR_OOM : TR_ERR_HIP, hipGetErrorString(e));
+    }
+    *out_mesh = m;
+    return TR_OK;
+}
+
+int tr_mesh_destroy(tr_context* c, tr_mesh* m) {
+    if (!c) return TR_ERR_INVALID;
+    if (!m) return TR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(m->pos); (void)hipFree(m->nrm); (void)hipFree(m->uvw); (void)hipFree(m->idx);
+    delete m;
+    return TR_OK;
+}
+
+int tr_texture_create(tr_context* c, const uint8_t* rgba8, int width, int height, tr_texture** out_tex) {
+    if (!c || !out_tex) return TR_ERR_INVALID;
+    *out_tex = nullptr;
+    if (!rgba8 || width < 1 || height < 1) return fail(c, TR_ERR_INVALID, "bad texture");
+    if (width > 32768 || height > 32768) return fail(c, TR_ERR_SIZE, "texture larger than 32768");
+    TR_HIP(c, hipSetDevice(c->device));
+    tr_texture* t = new (std::nothrow) tr_texture();
+    if (!t) return fail(c, TR_ERR_OOM, "host allocation failed");
+    t->w = width;
+    t->h = height;
+    size_t bytes = (size_t)width * height * 4;
+    hipError_t e = hipMalloc(&t->dev, bytes);
+    if (e == hipSuccess) e = hipMemcpy(t->dev, rgba8, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t->dev);
+        delete t;
+        return fail(c, e == hipErrorOutOfMemory ? TR_ERR_OOM : TR_ERR_HIP, hipGetErrorString(e));
+    }
+    *out_tex = t;
+    return TR_OK;
+}
+
+int tr_texture_destroy(tr_context* c, tr_texture* t) {
+    if (!c) return TR_ERR_INVALID;
+    if (!t) return TR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(t->dev);
+    delete t;
+    return TR_OK;
+}
+
+int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
+    if (!c || !mesh || !p) return TR_ERR_INVALID;
+    if (mesh->any_uv && (!p->diffuse || (p->use_normal_map && !p->normal_map)))
+        return fail(c, TR_ERR_INVALID, "mesh has texture coordinates but a texture is missing");
+    if (c->draw_count >= c->draw_cap) return fail(c, TR_ERR_SIZE, "more than 4096 draws since tr_clear");
+    if ((uint64_t)c->tri_total + (uint64_t)mesh->n_tris > (uint64_t)kTriSeqMax)
+        return fail(c, TR_ERR_SIZE, "more than 2^28-1 triangles since tr_clear");
+    TR_HIP(c, hipSetDevice(c->device));
+    c->resolved = false;
+    c->resolved_mask = 0;
+    if (mesh->n_tris == 0) {
+        c->draw_count++;
+        return TR_OK;
+    }
+    int rc = ensure_tri_capacity(c, (size_t)c->tri_total + (size_t)mesh->n_tris);
+    if (rc != TR_OK) return rc;
+    rc = ensure_scratch(c, &c->ndc, &c->ndc_cap, (size_t)mesh->n_pos * 3);
+    if (rc != TR_OK) return rc;
+    rc = ensure_scratch(c, &c->nout, &c->nout_cap, (size_t)(mesh->n_nrm ? mesh->n_nrm : 1) * 3);
+    if (rc != TR_OK) return rc;
+
+    Mat4 pmv, nmat;
+    std::memcpy(pmv.m, p->pmv, sizeof(pmv.m));
+    std::memcpy(nmat.m, p->normal_mat, sizeof(nmat.m));
+    {
+        ProfScope ps(c, ST_TRANSFORM);
+        int n = (int)(mesh->n_pos + mesh->n_nrm);
+        hipLaunchKernelGGL(k_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, mesh->pos, (int)mesh->n_pos,
+                           mesh->nrm, (int)mesh->n_nrm, pmv, nmat, c->ndc, c->nout);
+        TR_HIP(c, hipGetLastError());
+    }
+    const uint32_t tri_base = c->tri_total;
+    const uint32_t n_halves = 2u * (uint32_t)mesh->n_tris;
+    {
+        ProfScope ps(c, ST_SETUP);
+        SetupArgs sa;
+        sa.idx = mesh->idx; sa.pos = mesh->pos; sa.uvw = mesh->uvw; sa.ndc = c->ndc; sa.nout = c->nout;
+        sa.n_pos = (int)mesh->n_pos; sa.n_nrm = (int)mesh->n_nrm; sa.n_tris = (int)mesh->n_tris;
+        sa.tri_base = tri_base; sa.draw = c->draw_count; sa.W = c->W; sa.H = c->H;
+        // src/model_renderer/mod.rs:314-318: scale((W-1)/2,(H-1)/2,1) * translate(1,1,0)
+        Mat4 sc = {{(double)(c->W - 1) / 2.0, 0, 0, 0, 0, (double)(c->H - 1) / 2.0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+        Mat4 trn = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1.0, 1.0, 0.0, 1}};
+        sa.vpm = host_mat4_mul(sc, trn);
+        sa.nmat = nmat;
+        sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
+        DrawDev& d = sa.params;
+        std::memset(&d, 0, sizeof(d));
+        d.tex = p->diffuse ? p->diffuse->dev : nullptr;
+        d.tw = p->diffuse ? p->diffuse->w : 0;
+        d.th = p->diffuse ? p->diffuse->h : 0;
+        d.nm = p->normal_map ? p->normal_map->dev : nullptr;
+        d.nw = p->normal_map ? p->normal_map->w : 0;
+        d.nh = p->normal_map ? p->normal_map->h : 0;
+        // src/main.rs:249-251: Vector3::new(camera_pos).normalize(); norm^2 = (x*x + y*y) + z*z
+        {
+            double x = p->light_dir[0], y = p->light_dir[1], z = p->light_dir[2];
+            double n = std::sqrt(0.0 + ((x * x + y * y) + z * z));
+            d.light[0] = x / n; d.light[1] = y / n; d.light[2] = z / n;
+        }
+        d.ambient = p->ambient;
+        d.intensity = p->intensity;
+        for (int i = 0; i < 4; ++i) d.vcol[i] = p->vertex_color[i];
+        d.use_nm = p->use_normal_map && p->normal_map;
+        sa.draw_table = c->draw_table;
+        hipLaunchKernelGGL(k_setup, dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
+        TR_HIP(c, hipGetLastError());
+        // prefix of scanline counts, continuing from the previous draw's total
+        const uint32_t lo = 2u * tri_base;
+        uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
+        if (tiles == 1) {
+            hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
+                               c->half_off + lo, (const unsigned long long*)nullptr, c->flags);
+        } else {
+            hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo,
+                               n_halves, c->tile_sum);
+            hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(kScanThreads), 0, c->stream, c->tile_sum, tiles,
+                               c->half_off + lo, c->flags);
+            hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
+                               c->half_off + lo, (const unsigned long long*)c->tile_sum, c->flags);
+        }
+        TR_HIP(c, hipGetLastError());
+    }
+    {
+        ProfScope ps(c, ST_DEPTH);
+        rc = launch_raster(c, 0, 2u * tri_base, 2u * tri_base + n_halves);
+        if (rc != TR_OK) return rc;
+    }
+    c->tri_total += (uint32_t)mesh->n_tris;
+    c->draw_count++;
+    return TR_OK;
+}
+
+int tr_resolve(tr_context* c, uint32_t out_mask) {
+    if (!c) return TR_ERR_INVALID;
+    TR_HIP(c, hipSetDevice(c->device));
+    size_t npix = (size_t)c->W * c->H;
+    out_mask |= TR_OUT_RGBA8;
+    if ((out_mask & TR_OUT_Z) && !c->z_out) TR_HIP(c, hipMalloc(&c->z_out, npix * sizeof(double)));
+    if ((out_mask & TR_OUT_TRI_ID) && !c->tri_out) TR_HIP(c, hipMalloc(&c->tri_out, npix * sizeof(uint32_t)));
+    if ((out_mask & TR_OUT_RGBA_F64) && !c->rgba_f64) TR_HIP(c, hipMalloc(&c->rgba_f64, npix * 4 * sizeof(double)));
+    if (!c->resolved && c->tri_total) {
+        ProfScope ps(c, ST_WINNER);
+        int rc = launch_raster(c, 1, 0u, 2u * c->tri_total);
+        if (rc != TR_OK) return rc;
+    }
+    {
+        ProfScope ps(c, ST_SHADE);
+        ShadeArgs sa;
+        sa.wkey = c->wkey; sa.rast = c->rast; sa.shade = c->shade; sa.draws = c->draw_table; sa.nan = c->nan;
+        sa.W = c->W; sa.H = c->H; sa.out_mask = out_mask; sa.rgba8 = c->rgba8; sa.z_out = c->z_out;
+        sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.counters = c->counters;
+        TR_HIP(c, hipMemsetAsync(c->counters + 4, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_shade, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, sa);
+        TR_HIP(c, hipGetLastError());
+    }
+    c->resolved = true;
+    c->resolved_mask = out_mask;
+    return TR_OK;
+}
+
+int tr_read_z_f64(tr_context* c, double* out, int layout) {
+    if (!c || !out) return TR_ERR_INVALID;
+    int rc = need_plane(c, TR_OUT_Z);
+    if (rc != TR_OK) return rc;
+    return read_plane<double>(c, c->z_out, out, layout, 1);
+}
+
+int tr_read_triangle_id_u32(tr_context* c, uint32_t* out, int layout) {
+    if (!c || !out) return TR_ERR_INVALID;
+    int rc = need_plane(c, TR_OUT_TRI_ID);
+    if (rc != TR_OK) return rc;
+    return read_plane<uint32_t>(c, c->tri_out, out, layout, 1);
+}
+
+int tr_read_winner_key_u64(tr_context* c, uint64_t* out, int layout) {
+    if (!c || !out) return TR_ERR_INVALID;
+    int rc = need_plane(c, TR_OUT_RGBA8);
+    if (rc != TR_OK) return rc;
+    rc = read_plane<uint64_t>(c, (const uint64_t*)c->wkey, out, layout, 1);
+    if (rc != TR_OK) return rc;
+    NanTable nt;
+    TR_HIP(c, hipMemcpy(&nt, c->nan, sizeof(nt), hipMemcpyDeviceToHost));
+    for (uint32_t s = 0; s < kNanSlots; ++s)
+        if (nt.pix[s] != kNanEmpty && nt.first_nan[s] < nt.first_any[s]) {
+            size_t x = nt.pix[s] % (uint32_t)c->W, y = nt.pix[s] / (uint32_t)c->W;
+            size_t at = layout == TR_LAYOUT_ROW_MAJOR ? y * c->W + x : x * c->H + y;
+            out[at] = nt.first_nan[s];
+        }
+    return TR_OK;
+}
+
+int tr_read_rgba8(tr_context* c, uint8_t* out, int flip) {
+    if (!c || !out) return TR_ERR_INVALID;
+    int rc = need_plane(c, TR_OUT_RGBA8);
+    if (rc != TR_OK) return rc;
+    size_t row = (size_t)c->W * 4;
+    if (!flip) {
+        TR_HIP(c, hipMemcpyAsync(out, c->rgba8, row * c->H, hipMemcpyDeviceToHost, c->stream));
+        TR_HIP(c, hipStreamSynchronize(c->stream));
+    } else {  // src/helpers/mod.rs:214-218: image row = H-1-y
+        std::vector<uint8_t> tmp(row * c->H);
+        TR_HIP(c, hipMemcpyAsync(tmp.data(), c->rgba8, row * c->H, hipMemcpyDeviceToHost, c->stream));
+        TR_HIP(c, hipStreamSynchronize(c->stream));
+        for (int y = 0; y < c->H; ++y) std::memcpy(out + row * (size_t)(c->H - 1 - y), tmp.data() + row * y, row);
+    }
+    return TR_OK;
+}
+
+int tr_read_rgba_f64(tr_context* c, double* out, int layout) {
+    if (!c || !out) return TR_ERR_INVALID;
+    int rc = need_plane(c, TR_OUT_RGBA_F64);
+    if (rc != TR_OK) return rc;
+    return read_plane<double>(c, c->rgba_f64, out, layout, 4);
+}
+
+int tr_get_counters(tr_context* c, uint64_t out[8]) {
+    if (!c || !out) return TR_ERR_INVALID;
+    TR_HIP(c, hipSetDevice(c->device));
+    unsigned long long tmp[8];
+    TR_HIP(c, hipMemcpyAsync(tmp, c->counters, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
+    uint32_t total_scan = 0;
+    TR_HIP(c, hipMemcpyAsync(&total_scan, c->half_off + 2 * (size_t)c->tri_total, sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, c->stream));
+    TR_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i) out[i] = tmp[i];
+    out[2] = total_scan;
+    out[3] = c->tri_total;
+    return TR_OK;
+}
+
+int tr_get_status_flags(tr_context* c, uint32_t* out_flags) {
+    if (!c || !out_flags) return TR_ERR_INVALID;
+    TR_HIP(c, hipSetDevice(c->device));
+    TR_HIP(c, hipMemcpyAsync(out_flags, c->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    TR_HIP(c, hipStreamSynchronize(c->stream));
+    return TR_OK;
+}
+
+int tr_synchronize(tr_context* c) {
+    if (!c) return TR_ERR_INVALID;
+    TR_HIP(c, hipSetDevice(c->device));
+    TR_HIP(c, hipStreamSynchronize(c->stream));
+    return TR_OK;
+}
+
+int tr_get_stream(tr_context* c, void** out_hip_stream) {
+    if (!c || !out_hip_stream) return TR_ERR_INVALID;
+    *out_hip_stream = (void*)c->stream;
+    return TR_OK;
+}
+
+int tr_device_ptr_rgba8(tr_context* c, void** out_dev_ptr) {
+    if (!c || !out_dev_ptr) return TR_ERR_INVALID;
+    *out_dev_ptr = (void*)c->rgba8;
+    return TR_OK;
+}
+
+int tr_profile_enable(tr_context* c, int enable) {
+    if (!c) return TR_ERR_INVALID;
+    c->prof = enable != 0;
+    return TR_OK;
+}
+
+int tr_profile_read(tr_context* c, double ms[6], uint64_t counts[6], int reset) {
+    if (!c || !ms || !counts) return TR_ERR_INVALID;
+    for (int i = 0; i < ST_COUNT; ++i) {
+        ms[i] = c->prof_ms[i];
+        counts[i] = c->prof_n[i];
+        if (reset) {
+            c->prof_ms[i] = 0;
+            c->prof_n[i] = 0;
+        }
+    }
+    return TR_OK;
+}
+
+}  // extern "C"

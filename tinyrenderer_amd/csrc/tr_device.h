@@ -1,0 +1,160 @@
+// Device-side data layout and exact-arithmetic helpers for the gfx950 rasterizer.
+//
+// Numerics contract: every scalar is IEEE binary64, every
+// + - * / sqrt is individually rounded, nothing is fused or re-associated.  This file
+// is compiled with -ffp-contract=off and without fast-math; f64 divide and sqrt lower
+// to correctly rounded sequences on gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tr {
+
+// ---- limits of the 64-bit winner key: tri_seq:28 | half:1 | i:17 | j:18 ----
+constexpr uint32_t kResMax = 131070u;          // scanline count limit per half (i <= res)
+constexpr uint32_t kTriSeqMax = (1u << 28) - 1; // triangles per frame (all draws since clear)
+constexpr uint64_t kKeyNone = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kKeyTriShift = 36, kKeyHalfShift = 35, kKeyIShift = 18;
+constexpr uint32_t kNanSlots = 8;
+constexpr uint32_t kNanEmpty = 0xFFFFFFFFu;
+
+struct Mat4 {  // column-major, m[c*4+r] (nalgebra storage order)
+    double m[16];
+};
+
+// Per-triangle record read by the raster passes and by the shade pass to rebuild a sample:
+// the y-sorted viewport points S0,S1,S2 and the long-side split point
+// (reference: src/model_renderer/mod.rs:320-331,435-441).
+struct __attribute__((aligned(128))) TriRaster {
+    double s0[3], s1[3], s2[3], sp[3];
+    uint32_t res[2];  // resolution of half 0 / half 1 (mod.rs:363-369); 0 = no scanlines
+    uint32_t pad[6];
+};
+static_assert(sizeof(TriRaster) == 128, "TriRaster must be 128 B");
+
+// Per-triangle record read by the shade pass only (mod.rs:329,333-358,477-535).
+struct __attribute__((aligned(256))) TriShade {
+    double ux[3], uy[3];  // unsorted viewport x / y of the three corners
+    double n[3][3];       // vertex-shader normal xyz per corner (main.rs:164)
+    double uv[3][2];      // texture u,v per corner
+    double t[3], b[3];    // tangent / bitangent xyz (mod.rs:346-351)
+    uint32_t draw;        // index into the per-frame draw table
+    uint32_t flags;       // bit0 has_uv (all three corners), bit1 has_tb
+    uint32_t pad[4];
+};
+static_assert(sizeof(TriShade) == 256, "TriShade must be 256 B");
+
+// One draw call's fragment-shader constants (src/main.rs:173-267).
+struct DrawDev {
+    const uint32_t* tex;  // RGBA8, row-major, row 0 = bottom (already flipped)
+    const uint32_t* nm;
+    int32_t tw, th, nw, nh;
+    double light[3];  // normalize(camera_pos), main.rs:249-251
+    double ambient, intensity;
+    double vcol[4];  // VertexShaderResult.color (WHITE), main.rs:170
+    int32_t use_nm;
+    int32_t pad;
+};
+
+// Small side table for NaN-depth samples (SURVEY.md 7.1 caveat i): a NaN sample wins a
+// pixel iff it is the first sample to land on it in draw order.
+struct NanTable {
+    uint32_t pix[kNanSlots];        // pixel index or kNanEmpty
+    uint64_t first_nan[kNanSlots];  // min order key over NaN samples on that pixel
+    uint64_t first_any[kNanSlots];  // min order key over non-NaN samples on that pixel
+};
+
+// ------------------------------------------------------------ exact helpers
+// nalgebra gemv association: out[r] = ((M[r][0]*x + M[r][1]*y) + M[r][2]*z) + M[r][3]*w
+__device__ __forceinline__ void mat4_mul_vec4(const Mat4& a, double x, double y, double z, double w,
+                                              double out[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double acc = a.m[r] * x;
+        acc = a.m[4 + r] * y + acc;
+        acc = a.m[8 + r] * z + acc;
+        acc = a.m[12 + r] * w + acc;
+        out[r] = acc;
+    }
+}
+// nalgebra dot for static 3-vectors: (a+b)+c ; for 4-vectors: (a+c)+(b+d)
+__device__ __forceinline__ double dot3(double ax, double ay, double az, double bx, double by,
+                                       double bz) {
+    double p0 = ax * bx, p1 = ay * by, p2 = az * bz;
+    return (p0 + p1) + p2;
+}
+__device__ __forceinline__ void normalize3(double& x, double& y, double& z) {
+    double n = sqrt(0.0 + dot3(x, y, z, x, y, z));
+    x = x / n;
+    y = y / n;
+    z = z / n;
+}
+// Vector4 (x,y,z,0).normalize(): norm^2 = (x*x + z*z) + (y*y + 0*0); the w lane stays unused.
+__device__ __forceinline__ void normalize4_w0(double& x, double& y, double& z) {
+    double p0 = x * x, p1 = y * y, p2 = z * z, p3 = 0.0 * 0.0;
+    p0 += p2;
+    p1 += p3;
+    double n = sqrt(0.0 + (p0 + p1));
+    x = x / n;
+    y = y / n;
+    z = z / n;
+}
+
+// Monotone u64 image of a non-NaN double, with -0 folded onto +0 (the reference's
+// `current_z > dist` test cannot tell the zeros apart).
+__device__ __forceinline__ uint64_t encode_depth(double d) {
+    uint64_t b = (uint64_t)__double_as_longlong(d + 0.0);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Rust `v.ceil() as i64` followed by `.max(2)` for v >= 0 or NaN; values above `limit`
+// are reported as limit+1 so the caller can flag them.
+__device__ __forceinline__ uint32_t res_from_extent(double m, uint32_t limit) {
+    double c = ceil(m);
+    if (!(c > 2.0)) return 2u;  // NaN, <= 2
+    if (c > (double)limit) return limit + 1u;
+    return (uint32_t)c;
+}
+
+// Pixel coordinate of `round(v) as i64` tested against [0, n-1]: returns -1 if outside.
+// NaN rounds to 0 (Rust saturating cast), -0.0 is inside.
+__device__ __forceinline__ int pixel_coord(double v, int n) {
+    double r = round(v);
+    if (r != r) return 0;
+    if (r < 0.0 || r > (double)(n - 1)) return -1;
+    return (int)r;
+}
+
+// The sample enumeration of one scanline end-point pair (segment_3d/mod.rs:26-33,41-48):
+// given the half's apex a1 and the two far ends a2 (short edge) and b2 (split point),
+// scanline i of `res` has A = a1 + t*(a2-a1), B = a1 + t*(b2-a1), t = i * (1/res).
+struct Scanline {
+    double ax, ay, az, dx, dy, dz;  // A and B-A
+    uint32_t hres;                  // horizontal resolution (>= 2), or kBig+1 if too long
+};
+__device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t half, uint32_t i) {
+    const double* a1 = half ? r.s2 : r.s0;
+    const double* a2 = r.s1;
+    const double* b2 = r.sp;
+    double delta = 1.0 / (double)r.res[half];
+    double t = (double)i * delta;
+    double Ax = a1[0] + t * (a2[0] - a1[0]);
+    double Ay = a1[1] + t * (a2[1] - a1[1]);
+    double Az = a1[2] + t * (a2[2] - a1[2]);
+    double Bx = a1[0] + t * (b2[0] - a1[0]);
+    double By = a1[1] + t * (b2[1] - a1[1]);
+    double Bz = a1[2] + t * (b2[2] - a1[2]);
+    Scanline s;
+    s.ax = Ax; s.ay = Ay; s.az = Az;
+    s.dx = Bx - Ax; s.dy = By - Ay; s.dz = Bz - Az;
+    // (ceil(max(|dx|,|dy|)) as i64 + 1).max(2)
+    double c = ceil(fmax(fabs(s.dx), fabs(s.dy)));
+    uint32_t h;
+    if (c != c) h = 1u;                        // NaN as i64 = 0, +1
+    else if (c > 262142.0) h = 262144u;        // beyond the key's j field; setup prevents this
+    else h = (uint32_t)c + 1u;
+    s.hres = h < 2u ? 2u : h;
+    return s;
+}
+
+}  // namespace tr

@@ -1,0 +1,47 @@
+"""The reference's scene parameters (src/main.rs:12-43,57-116) as reusable builders.
+
+These are the literals of `main`: camera at (0,0,2) looking at the origin, perspective
+(near=10, far=1, fov=0.35*pi, aspect=W/H), head rotation 0.025*time about the first euler
+angle, eye mesh parented to the head.  BASELINE.json's configs re-parameterise them.
+"""
+import math
+import os
+
+from . import helpers as H
+from .model_renderer import BuiltinShader, MeshComponent
+
+AFRICAN_HEAD = ("african_head/african_head.obj", "african_head/african_head_diffuse.png",
+                "african_head/african_head_nm_tangent.png")
+AFRICAN_HEAD_EYE_INNER = ("african_head/african_head_eye_inner.obj",
+                          "african_head/african_head_eye_inner_diffuse.png",
+                          "african_head/african_head_eye_inner_nm_tangent.png")
+DIABLO = ("diablo_guy/diablo3_pose.obj", "diablo_guy/diablo3_pose_diffuse.png",
+          "diablo_guy/diablo3_pose_nm_tangent.png")
+
+
+def load_component(triple, asset_dir=None):
+    d = asset_dir or H.ASSET_DIR
+    return MeshComponent.from_paths(*(os.path.join(d, p) for p in triple))
+
+
+def camera(eye=(0.0, 0.0, 2.0)):
+    """main.rs:62-70: camera_pos and the look-at (view) matrix."""
+    return tuple(eye), H.look_at_rh(eye, (0.0, 0.0, 0.0), (0.0, 1.0, 0.0))
+
+
+def orbit_eye(k, n_views, radius=2.0):
+    """eye_k = 2*(sin t, 0, cos t), t = 2*pi*k/n."""
+    t = 2.0 * math.pi * k / n_views
+    return (radius * math.sin(t), 0.0, radius * math.cos(t))
+
+
+def perspective(frame_width, frame_height):
+    """main.rs:110-116."""
+    return H.make_perspective_matrix(10.0, 1.0, 0.35 * math.pi, frame_width / frame_height)
+
+
+def shader_for(mesh_component, frame_width, frame_height, eye=(0.0, 0.0, 2.0), use_normal_map=True):
+    """main.rs:118-142: model_view = view * local_to_world; normal matrix = (MV^T)^-1."""
+    cam_pos, view = camera(eye)
+    mv = H.mat4_mul(view, mesh_component.local_to_world_matrix())
+    return BuiltinShader(perspective(frame_width, frame_height), mv, cam_pos, use_normal_map=use_normal_map)
