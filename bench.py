@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s (+ Mfragments/s) of the reference's african_head scene at
+3840x2160 through the HIP path, with the shade pass priced against the HBM roofline and the
+C++ oracle (a restatement of the reference, NOT the Rust binary) timed on the host beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one frame: tr_clear + tr_draw + tr_resolve (the window the reference prints as
+"Frametime (nosync)", src/main.rs:58-60,295).  Mesh and textures are resident in HBM before
+the timed region.  N > 1 (launched by torch.distributed.run) shards independent frames over
+ranks with no data-path collective: weak scaling, value = total frames / max-over-ranks time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_scene(W, H):
+    import scene_util as SU
+    from tinyrenderer_amd import scenes
+
+    head = SU.component("head")
+    head.transform.set_rotation((0.025, 0.0, 0.0))  # frame time = 1, src/main.rs:92-94
+    return [(head, scenes.shader_for(head, W, H))]
+
+
+def cpu_baseline(W, H, draws, budget_s=12.0):
+    """Oracle ('port' of the reference, single thread) on the same frame; bounded sample."""
+    import oracle_ffi as O
+
+    st = O.OracleState(W, H)
+    imgs = {}
+    for mc, _ in draws:
+        for img in (mc.texture, mc.normal_map):
+            if id(img) not in imgs:
+                imgs[id(img)] = O.OracleImage(img[::-1], flip=True)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_all < budget_s and len(times) < 40):
+        t0 = time.perf_counter()
+        st.clear_screen()
+        for mc, sh in draws:
+            rc = st.render_mesh_component(mc.mesh, sh, imgs[id(mc.texture)], imgs[id(mc.normal_map)])
+            assert rc == 0
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times[1:]))
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times) - 1} frames of the same {W}x{H} african_head frame (median), "
+                      "C++ restatement of the reference (oracle/), single thread, clear + draw, no present",
+            "ms_per_frame": med * 1e3, "fragments_per_frame": st.counters()["fragments"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-frames", type=int, default=30)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ModelRendererState, make_draw_params
+
+    lib = _ffi.load()
+    W, H = args.width, args.height
+    draws = build_scene(W, H)
+    st = ModelRendererState(W, H, device=local_rank)
+    ctx = st._ctx
+    prepared = [(st._mesh_handle(mc.mesh), make_draw_params(st, sh, mc.texture, mc.normal_map)) for mc, sh in draws]
+
+    def frame():
+        lib.tr_clear(ctx)
+        for mesh_h, params in prepared:
+            rc = lib.tr_draw(ctx, mesh_h, C.byref(params))
+            if rc != 0:
+                _ffi.check(ctx, rc, "tr_draw")
+        rc = lib.tr_resolve(ctx, _ffi.TR_OUT_RGBA8)
+        if rc != 0:
+            _ffi.check(ctx, rc, "tr_resolve")
+
+    def sync():
+        lib.tr_synchronize(ctx)
+        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        frame()
+    sync()
+    counters = st.counters()
+    flags = st.status_flags()
+    assert flags == 0, f"status flags {flags:#x}"
+
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_frames = args.steps * world
+    fps = total_frames / elapsed
+    frags = counters["fragments"]
+
+    # ---- per-stage GPU time with hipEvents on the library's own stream (separate loop:
+    # event-bracketing every launch serialises the host, so it is not part of `value`)
+    stage_names = ["clear", "transform", "setup_scan", "depth_pass", "winner_pass", "shade"]
+    lib.tr_profile_enable(ctx, 1)
+    ms = (C.c_double * 6)()
+    cnt = (C.c_uint64 * 6)()
+    lib.tr_profile_read(ctx, ms, cnt, 1)
+    for _ in range(args.profile_frames):
+        frame()
+    sync()
+    lib.tr_profile_read(ctx, ms, cnt, 1)
+    lib.tr_profile_enable(ctx, 0)
+    stages_us = {n: (ms[i] / max(1, cnt[i])) * 1e3 for i, n in enumerate(stage_names)}
+
+    # ---- algorithmic bytes of the shade pass (SURVEY.md 8(d) / DESIGN.md):
+    # W*H*(8 B winner-key read + 4 B RGBA8 write) + visible_tris*320 B + sum(min(texture bytes, shaded_px*16 B))
+    tri = st.triangle_ids(_ffi.TR_LAYOUT_ROW_MAJOR)
+    shaded_px = int((tri != 0xFFFFFFFF).sum())
+    vis_tris = int(np.unique(tri[tri != 0xFFFFFFFF]).size)
+    tex_bytes = 0
+    seen = set()
+    for mc, _ in draws:
+        for img in (mc.texture, mc.normal_map):
+            if id(img) not in seen:
+                seen.add(id(img))
+                tex_bytes += min(img.shape[0] * img.shape[1] * 4, shaded_px * 16)
+    shade_bytes = W * H * 12 + vis_tris * 320 + tex_bytes
+    shade_s = stages_us["shade"] * 1e-6
+    achieved = shade_bytes / shade_s / 1e9 if shade_s > 0 else 0.0
+
+    out = {
+        "metric": "frames/sec at 4K (african_head 3840x2160, clear+draw+resolve)",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "reference assets (african_head.obj + diffuse/nm_tangent PNG), fixed frame time=1",
+        "config": {"workload": f"african_head {W}x{H} single frame, 1 draw (BASELINE.json configs[2])",
+                   "frames_per_rank_per_step": 1, "parallelism": f"views x{world}" if world > 1 else "single GPU"},
+        "mfragments_per_s": fps * frags / 1e6,
+        "fragments_per_frame": frags, "samples_per_frame": counters["samples"], "shaded_px_per_frame": shaded_px,
+        "stages_us": stages_us,
+        "roofline": {"bound": "hbm", "kernel": "k_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": shade_bytes, "avg_launch_us": stages_us["shade"]},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(W, H, draws)
+    st.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
