@@ -17,6 +17,7 @@ constexpr uint64_t kKeyNone = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kKeyTriShift = 36, kKeyHalfShift = 35, kKeyIShift = 18;
 constexpr uint32_t kNanSlots = 8;
 constexpr uint32_t kNanEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kCounterSlots = 1024;  // 64-byte counter slots, summed on read
 
 struct Mat4 {  // column-major, m[c*4+r] (nalgebra storage order)
     double m[16];

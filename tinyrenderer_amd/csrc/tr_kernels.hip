@@ -342,8 +342,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __r
 }
 
 // =============================================================== (3) raster
-// One wave per chunk of 64 consecutive scanlines of the frame-global scanline sequence.
-// Lanes first own one scanline each (find its half by binary search in half_off, build A and
+// One workgroup per chunk of 64 consecutive scanlines of the frame-global scanline sequence.
+// Lanes of wave 0 first own one scanline each (find its half by binary search in half_off, build A and
 // B-A, count its samples), the wave scans the counts, then lanes own SAMPLES: consecutive
 // lanes take consecutive samples of a scanline, i.e. consecutive pixels of a row, so the
 // depth / winner atomics of one wave-instruction fall into contiguous 8-byte slots.
@@ -360,17 +360,18 @@ struct RasterArgs {
     NanTable* nan;
 };
 
-constexpr int kRasterWaves = 1;  // waves per block (block = 64 threads)
+constexpr int kRasterThreads = 256;  // wave 0 builds the chunk's scanlines, all 4 waves enumerate samples
 
-template <int PASS>
-__global__ __launch_bounds__(64) void k_raster(RasterArgs a) {
+template <int PASS, bool PRECHECK>
+__global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     __shared__ double sA[3][64];
     __shared__ double sD[3][64];
     __shared__ double sInv[64];
     __shared__ unsigned long long sKey[64];
     __shared__ uint32_t sPre[65];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool wave0 = threadIdx.x < 64;
     const uint32_t s_begin = a.half_off[a.h_lo];
     const uint32_t s_end = a.half_off[a.h_hi];
     const uint32_t n_scan = s_end - s_begin;
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64) void k_raster(RasterArgs a) {
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         // ---- scanline phase
         uint32_t g = s_begin + chunk * 64u + (uint32_t)lane;
-        bool valid = g < s_end;
+        bool valid = wave0 && g < s_end;
         uint32_t cnt = 0;
         if (valid) {
             uint32_t lo = a.h_lo, hi = a.h_hi;  // half_off[lo] <= g < half_off[hi]
@@ -411,13 +412,15 @@ __global__ __launch_bounds__(64) void k_raster(RasterArgs a) {
             uint32_t t = __shfl_up(inc, d, 64);
             if (lane >= d) inc += t;
         }
-        sPre[lane + 1] = inc;
-        if (lane == 0) sPre[0] = 0;
+        if (wave0) {
+            sPre[lane + 1] = inc;
+            if (lane == 0) sPre[0] = 0;
+        }
         __syncthreads();
         const uint32_t total = sPre[64];
 
         // ---- sample phase
-        for (uint32_t k = (uint32_t)lane; k < total; k += 64u) {
+        for (uint32_t k = threadIdx.x; k < total; k += (uint32_t)kRasterThreads) {
             uint32_t sidx = 0;
 #pragma unroll
             for (uint32_t step = 32; step; step >>= 1)
@@ -449,13 +452,13 @@ __global__ __launch_bounds__(64) void k_raster(RasterArgs a) {
                 } else {
                     if (dist == -__builtin_huge_val()) atomicOr(a.flags, 1u << 3);
                     unsigned long long e = encode_depth(dist);
-                    if (e < a.depth[pix]) atomicMin(&a.depth[pix], e);
+                    if (!PRECHECK || e < a.depth[pix]) atomicMin(&a.depth[pix], e);
                 }
             } else {
                 unsigned long long key = sKey[sidx] | (unsigned long long)j;
                 if (!isnan_d) {
                     unsigned long long e = encode_depth(dist);
-                    if (a.depth[pix] == e && key < a.wkey[pix]) atomicMin(&a.wkey[pix], key);
+                    if (a.depth[pix] == e && (!PRECHECK || key < a.wkey[pix])) atomicMin(&a.wkey[pix], key);
                 }
                 if (nan_active) {
                     for (uint32_t s = 0; s < kNanSlots; ++s) {
@@ -476,14 +479,18 @@ __global__ __launch_bounds__(64) void k_raster(RasterArgs a) {
             cnt_inb += __shfl_down(cnt_inb, d, 64);
         }
         if (lane == 0 && cnt_samples) {
-            atomicAdd(&a.counters[0], cnt_samples);
-            atomicAdd(&a.counters[1], cnt_inb);
+            // one 64-byte slot per block (mod kCounterSlots): same-address atomics serialise
+            unsigned long long* slot = a.counters + (size_t)(blockIdx.x % kCounterSlots) * 8;
+            atomicAdd(&slot[0], cnt_samples);
+            atomicAdd(&slot[1], cnt_inb);
         }
     }
 }
 
-template __global__ void k_raster<0>(RasterArgs);
-template __global__ void k_raster<1>(RasterArgs);
+template __global__ void k_raster<0, true>(RasterArgs);
+template __global__ void k_raster<1, true>(RasterArgs);
+template __global__ void k_raster<0, false>(RasterArgs);
+template __global__ void k_raster<1, false>(RasterArgs);
 
 // ================================================================ (4) shade
 struct ShadeArgs {
@@ -499,7 +506,7 @@ struct ShadeArgs {
     uint32_t* tri_out;  // optional
     double* rgba_f64;   // optional, 4 per pixel
     uint32_t* flags;
-    unsigned long long* counters;
+    unsigned long long* cov_counters;  // kCounterSlots x 8, [0] of each slot used
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -560,7 +567,8 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     (void)nan_win;
     bool has = key != kKeyNone;
     unsigned long long nwin = __popcll(__ballot(has));
-    if ((threadIdx.x & 63) == 0 && nwin) atomicAdd(&a.counters[4], nwin);
+    if ((threadIdx.x & 63) == 0 && nwin)
+        atomicAdd(&a.cov_counters[(size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8], nwin);
     if (!live) return;
     double col[4] = {0.0, 0.0, 0.0, 255.0};  // BLACK, helpers/mod.rs:22
     double zval = -__builtin_huge_val();
@@ -640,10 +648,8 @@ __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* p, size_t 
     for (; i < n; i += stride) p[i] = v;
 }
 
-__global__ void k_reset_frame(unsigned long long* counters, uint32_t* flags, NanTable* nan,
-                              uint32_t* half_off) {
+__global__ void k_reset_frame(uint32_t* flags, NanTable* nan, uint32_t* half_off) {
     int t = threadIdx.x;
-    if (t < 8) counters[t] = 0;
     if (t == 0) { *flags = 0; half_off[0] = 0; }
     if (t < (int)kNanSlots) {
         nan->pix[t] = kNanEmpty;
