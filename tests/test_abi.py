@@ -1,0 +1,62 @@
+"""The C-ABI library loads and exports every symbol include/tinyrenderer_hip.h declares; with
+no GPU present the product fails loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tinyrenderer_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "tinyrenderer_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    lib = _ffi.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(_ffi.EXPORTS) == names
+    assert b"gfx950" in lib.tr_version()
+
+
+def test_no_silent_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _ffi.load()
+    ctx = C.c_void_p()
+    assert lib.tr_create(0, 64, 64, C.byref(ctx)) == -3  # TR_ERR_NO_DEVICE
+    assert not ctx.value
+    from tinyrenderer_amd.model_renderer import ModelRendererState
+
+    with pytest.raises(_ffi.TrError):
+        ModelRendererState(64, 64)
+
+
+def test_argument_validation_without_gpu():
+    lib = _ffi.load()
+    assert lib.tr_create(0, 0, 10, C.byref(C.c_void_p())) == -6  # TR_ERR_SIZE
+    assert lib.tr_clear(None) == -1
+    assert lib.tr_draw(None, None, None) == -1
+    assert lib.tr_last_error(None) == b"null context"
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path must never import, link, load or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "tinyrenderer_amd")
+    banned = ("liboracle", "oracle_ffi", "import oracle", "from oracle", "oracle/", "tr_oracle")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="replace").read().lower()
+                for b in banned:
+                    assert b not in text, f"{os.path.join(dirpath, f)} references {b!r}"

@@ -89,3 +89,102 @@ def test_determinism():
         if ref is None:
             ref = h
         assert h == ref
+
+
+def _synthetic_component(obj, seed=3):
+    import numpy as np
+    from tinyrenderer_amd.model_renderer import MeshComponent
+
+    rng = np.random.default_rng(seed)
+    tex = rng.integers(0, 256, size=(32, 48, 4), dtype=np.uint8)
+    nm = rng.integers(0, 256, size=(16, 16, 4), dtype=np.uint8)
+    return MeshComponent(obj, tex, nm)
+
+
+def test_rando_triangle_face_normal_fallback(oracle):
+    """helpers/mod.rs:558-608: one triangle, UVs, no normals -> face normal (mod.rs:245-258)."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    mc = _synthetic_component(H.get_rando_mesh_object())
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.3, 0.2, 2.0))
+    for W, Hh in ((24, 24), (97, 61)):
+        o = SU.oracle_render(oracle, W, Hh, [(mc, sh)])
+        g = SU.gpu_render(W, Hh, [(mc, sh)])
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0 and info["covered"] > 0
+
+
+def test_mesh_without_uv_uses_vertex_colour(oracle):
+    """No texture coordinates: albedo = interpolated vertex colour (main.rs:243-244), no TBN."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    N = H.NONE_INDEX
+    obj = H.Object([[-0.8, -0.7, 0.1], [0.9, -0.2, -0.3], [0.1, 0.8, 0.4], [-0.3, 0.2, 0.9]],
+                   np.zeros((0, 3)), [[0, 0, 1], [0, 1, 0], [1, 0, 0]],
+                   [[0, N, 0, 1, N, 1, 2, N, 2], [0, N, 2, 2, N, 1, 3, N, N]])
+    mc = _synthetic_component(obj)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.5, 2.0), vertex_color=(200.0, 100.0, 50.0, 255.0))
+    o = SU.oracle_render(oracle, 80, 60, [(mc, sh)])
+    g = SU.gpu_render(80, 60, [(mc, sh)])
+    info = SU.assert_parity(o, g)
+    assert info["f64_colour_mismatches"] == 0 and info["covered"] > 0
+
+
+def test_nan_depth_degenerate_triangle(oracle):
+    """SURVEY.md 8(c) KAT 7: a horizontal degenerate triangle stores NaN at pixel (0,0) when it
+    arrives on a clear pixel, and loses when a valid sample got there first."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    N = H.NONE_INDEX
+    degenerate = H.Object([[-0.5, 0.25, 0.0], [0.5, 0.25, 0.0], [0.0, 0.25, 0.0]],
+                          [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)),
+                          [[0, 0, N, 1, 1, N, 2, 2, N]])
+    big = H.Object([[-1, -1, 0.5], [1, -1, 0.5], [-1, 1, 0.5]], np.zeros((0, 3)), np.zeros((0, 3)),
+                   [[0, N, N, 1, N, N, 2, N, N]])
+    d, b = _synthetic_component(degenerate), _synthetic_component(big)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    for order in ((d, b), (b, d)):
+        draws = [(mc, sh) for mc in order]
+        o = SU.oracle_render(oracle, 16, 16, draws)
+        g = SU.gpu_render(16, 16, draws)
+        SU.assert_parity(o, g)
+        assert np.isnan(o["z"][0, 0]) == (order[0] is d)
+
+
+def test_offscreen_and_culled(oracle):
+    """Triangles partly / fully outside the frustum: per-corner cull (mod.rs:293-312) and the
+    bounds test (mod.rs:380-386); no clipping exists in the reference."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    N = H.NONE_INDEX
+    obj = H.Object([[-1.6, -0.2, 0.0], [0.4, 1.7, 0.2], [0.3, -0.4, -0.1],      # partly outside
+                    [1.2, 1.3, 0.0], [1.9, 1.2, 0.0], [1.5, 1.8, 0.0],          # all outside: culled
+                    [0.0, 0.0, 1.5], [0.5, 0.0, 0.5], [0.0, 0.5, 0.5]],          # one corner z-outside
+                   [[0.1, 0.2, 0], [0.9, 0.3, 0], [0.4, 0.95, 0]], [[0, 0, 1]],
+                   [[0, 0, 0, 1, 1, 0, 2, 2, 0], [3, 0, 0, 4, 1, 0, 5, 2, 0], [6, 0, 0, 7, 1, 0, 8, 2, 0]])
+    mc = _synthetic_component(obj)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    o = SU.oracle_render(oracle, 120, 90, [(mc, sh)])
+    g = SU.gpu_render(120, 90, [(mc, sh)])
+    SU.assert_parity(o, g)
+    assert o["counters"]["culled"] == 1
+    assert g["counters"]["samples"] == o["counters"]["samples"]
+    assert g["counters"]["fragments"] == o["counters"]["fragments"] < o["counters"]["samples"]
+
+
+def test_empty_frame_and_empty_mesh(oracle):
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    empty = H.Object(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 9), dtype=np.uint32))
+    mc = _synthetic_component(empty)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    for draws in ([], [(mc, sh)]):
+        g = SU.gpu_render(33, 17, draws)
+        assert np.isneginf(g["z"]).all() and (g["seq"] == -1).all()
+        assert (g["present"] == np.array([0, 0, 0, 255], dtype=np.uint8)).all()
+        assert (g["fb"] == np.array([0.0, 0.0, 0.0, 255.0])).all()

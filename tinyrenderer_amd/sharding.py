@@ -1,0 +1,66 @@
+"""Multi-GPU partitioning of the render path: one process per GPU, no data-path collective.
+
+The path shards two ways; both are exchange-free until one final gather:
+  * views: independent camera views, a contiguous block per rank (config 5);
+  * bands: horizontal bands of 16-pixel tile rows of ONE frame (config 4) -- exact because the
+    per-pixel result is a pure min over the samples that land on that pixel.
+The only collective is the delivery gather of finished RGBA8 frames / bands to rank 0
+(RCCL over xGMI on GPUs: backend "nccl"; "gloo" on CPU for tests).
+"""
+import torch
+import torch.distributed as dist
+
+TILE = 16
+
+
+def shard_range(n, rank, world):
+    """Contiguous block [lo, hi) of n items for `rank`; blocks differ by at most one item."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def band_rows(height, rank, world, tile=TILE):
+    """Band [y_lo, y_hi) of pixel rows for `rank`: whole tile rows, contiguous, covering the frame."""
+    n_tile_rows = (height + tile - 1) // tile
+    lo, hi = shard_range(n_tile_rows, rank, world)
+    return min(lo * tile, height), min(hi * tile, height)
+
+
+def gather_frames(local, n_total, dst=0):
+    """Gather per-rank blocks of finished frames (n_local, H, W) uint8/int32 onto `dst` in view
+    order.  Returns the (n_total, H, W) tensor on dst, None elsewhere."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return local
+    max_n = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
+    pad = torch.zeros((max_n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(bufs[r][: hi - lo])
+    return torch.cat(parts, dim=0)
+
+
+def gather_bands(local_band, height, dst=0, tile=TILE):
+    """Gather per-rank bands (rows [y_lo, y_hi) of one frame, shape (rows, W[, C])) onto `dst`
+    and stack them into the (height, W[, C]) frame."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        return local_band
+    spans = [band_rows(height, r, world, tile) for r in range(world)]
+    max_rows = max(hi - lo for lo, hi in spans)
+    pad = torch.zeros((max_rows,) + tuple(local_band.shape[1:]), dtype=local_band.dtype, device=local_band.device)
+    pad[: local_band.shape[0]] = local_band
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(spans)], dim=0)
