@@ -125,7 +125,7 @@ def test_mesh_without_uv_uses_vertex_colour(oracle):
                    np.zeros((0, 3)), [[0, 0, 1], [0, 1, 0], [1, 0, 0]],
                    [[0, N, 0, 1, N, 1, 2, N, 2], [0, N, 2, 2, N, 1, 3, N, N]])
     mc = _synthetic_component(obj)
-    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.5, 2.0), vertex_color=(200.0, 100.0, 50.0, 255.0))
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.5, 2.0))  # vertex colour is WHITE as in main.rs:170
     o = SU.oracle_render(oracle, 80, 60, [(mc, sh)])
     g = SU.gpu_render(80, 60, [(mc, sh)])
     info = SU.assert_parity(o, g)
