@@ -52,7 +52,17 @@ enum {
     TR_FLAG_NEG_INF_DEPTH = 1u << 3, /* a sample with dist == -inf (reference re-opens the pixel;
                                         not reproduced) */
     TR_FLAG_SCANLINE_OVERFLOW = 1u << 4, /* more than 2^32-1 scanlines in one frame */
-    TR_FLAG_NAN_PIXEL_OVERFLOW = 1u << 5 /* more NaN-depth pixels than the side table holds */
+    TR_FLAG_NAN_PIXEL_OVERFLOW = 1u << 5, /* more NaN-depth pixels than the side table holds
+                                             (global-atomic raster mode only) */
+    TR_FLAG_BIN_OVERFLOW = 1u << 6  /* transient: the tile bin list was too small; the next call that
+                                       synchronises (reads, counters, flags) grows it and redoes the
+                                       resolve, then clears the bit */
+};
+
+/* Raster strategies (same results, bit for bit). */
+enum {
+    TR_RASTER_GLOBAL = 0, /* samples enumerated frame-wide, 64-bit atomicMin on HBM planes */
+    TR_RASTER_TILE = 1    /* default: triangles binned to 16x16 tiles, depth/winner tiles in LDS */
 };
 
 /* Buffer layouts for the tr_read_* calls. */
@@ -128,11 +138,19 @@ int tr_read_winner_key_u64(tr_context* ctx, uint64_t* out, int layout);
 int tr_read_rgba8(tr_context* ctx, uint8_t* out, int flip);
 int tr_read_rgba_f64(tr_context* ctx, double* out, int layout);
 
-/* Counters since tr_clear: [0] samples enumerated, [1] in-bounds z-tested samples
- * ("fragments", src/model_renderer/mod.rs:380-389), [2] scanlines, [3] triangles submitted,
- * [4] pixels with a winner (valid after tr_resolve), [5..7] reserved. */
+/* Counters since tr_clear: [1] in-bounds z-tested samples ("fragments",
+ * src/model_renderer/mod.rs:380-389; valid after tr_resolve in tile mode), [3] triangles
+ * submitted, [4] pixels with a winner (valid after tr_resolve); [0] samples enumerated and
+ * [2] scanlines are only counted by TR_RASTER_GLOBAL (0 otherwise); [5..7] reserved. */
 int tr_get_counters(tr_context* ctx, uint64_t out[8]);
 int tr_get_status_flags(tr_context* ctx, uint32_t* out_flags);
+
+/* Multi-GPU band sharding (no reference analogue; exact because a pixel's result is a pure min
+ * over the samples landing on it): restrict this context to pixel rows [y_lo, y_hi), whole
+ * 16-pixel tile rows.  Call after tr_clear and before the first draw; rows outside the band read
+ * back as cleared.  tr_set_raster_mode switches strategy under the same rule. */
+int tr_set_band(tr_context* ctx, int y_lo, int y_hi);
+int tr_set_raster_mode(tr_context* ctx, int mode);
 
 /* Plumbing for callers that keep data on the GPU (no reference analogue). */
 int tr_synchronize(tr_context* ctx);
@@ -140,7 +158,8 @@ int tr_get_stream(tr_context* ctx, void** out_hip_stream);
 int tr_device_ptr_rgba8(tr_context* ctx, void** out_dev_ptr); /* u32[W*H], row-major */
 /* Per-stage GPU time in ms accumulated since the last call with reset != 0, measured with
  * hipEvents on the context's stream when profiling is enabled:
- * [0] clear [1] transform [2] setup+scan [3] depth pass [4] winner pass [5] shade;
+ * [0] clear [1] transform [2] setup(+scan) [3] binning (tile mode) / depth pass (global mode)
+ * [4] tile raster (tile mode) / winner pass (global mode) [5] shade;
  * counts[i] = number of launches accumulated. */
 int tr_profile_enable(tr_context* ctx, int enable);
 int tr_profile_read(tr_context* ctx, double ms[6], uint64_t counts[6], int reset);

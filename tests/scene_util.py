@@ -49,10 +49,13 @@ def oracle_render(oracle, W, H, draws):
             "present": st.present(), "counters": st.counters()}
 
 
-def gpu_render(W, H, draws, device=0):
-    st = ModelRendererState(W, H, device=device)
+def gpu_render(W, H, draws, device=0, mode=None, band=None):
+    """mode: None (library default = tile raster), _ffi.TR_RASTER_TILE or _ffi.TR_RASTER_GLOBAL."""
+    st = ModelRendererState(W, H, device=device, raster_mode=mode)
     try:
         clear_screen(st)
+        if band is not None:
+            st.set_band(*band)
         for mc, sh in draws:
             render_mesh_component(st, mc, sh)
         st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z | _ffi.TR_OUT_TRI_ID | _ffi.TR_OUT_RGBA_F64)

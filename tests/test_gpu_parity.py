@@ -22,46 +22,54 @@ def _head_scene(W, H, rot=0.025, eye=(0.0, 0.0, 2.0), with_eye=False):
     return draws
 
 
-@pytest.mark.parametrize("W,H", [(64, 64), (128, 96), (200, 200), (853, 480)])
-def test_head_small(oracle, W, H):
+MODES = [pytest.param(1, id="tile"), pytest.param(0, id="global")]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("W,H", [(64, 64), (128, 96), (200, 200), (853, 480), (333, 517)])
+def test_head_small(oracle, W, H, mode):
     draws = _head_scene(W, H)
     o = SU.oracle_render(oracle, W, H, draws)
-    g = SU.gpu_render(W, H, draws)
+    g = SU.gpu_render(W, H, draws, mode=mode)
     info = SU.assert_parity(o, g)
-    assert g["counters"]["samples"] == o["counters"]["samples"]
     assert g["counters"]["fragments"] == o["counters"]["fragments"]
-    assert g["counters"]["scanlines"] == o["counters"]["scanlines"]
+    if mode == 0:  # only the global raster enumerates (and counts) out-of-bounds samples
+        assert g["counters"]["samples"] == o["counters"]["samples"]
+        assert g["counters"]["scanlines"] == o["counters"]["scanlines"]
     assert info["f64_colour_mismatches"] == 0
 
 
-def test_config1_head_800(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_config1_head_800(oracle, mode):
     """BASELINE.json configs[0]: african_head 800x800."""
     draws = _head_scene(800, 800)
     o = SU.oracle_render(oracle, 800, 800, draws)
-    g = SU.gpu_render(800, 800, draws)
+    g = SU.gpu_render(800, 800, draws, mode=mode)
     info = SU.assert_parity(o, g)
     assert o["counters"]["samples"] == 1087161 and info["covered"] == 211671  # SURVEY.md section 6
     assert g["counters"]["covered_pixels"] == 211671
     assert info["f64_colour_mismatches"] == 0
 
 
-def test_config2_diablo_1024(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_config2_diablo_1024(oracle, mode):
     """BASELINE.json configs[1] (without the shadow pass, which has no reference)."""
     mc = SU.component("diablo")
     mc.transform.set_rotation((0.025, 0.0, 0.0))
     draws = [(mc, scenes.shader_for(mc, 1024, 1024))]
     o = SU.oracle_render(oracle, 1024, 1024, draws)
-    g = SU.gpu_render(1024, 1024, draws)
+    g = SU.gpu_render(1024, 1024, draws, mode=mode)
     info = SU.assert_parity(o, g)
     assert o["counters"]["samples"] == 1294206 and info["covered"] == 173184
     assert info["f64_colour_mismatches"] == 0
 
 
-def test_two_draws_head_and_eye(oracle):
+@pytest.mark.parametrize("mode", MODES)
+def test_two_draws_head_and_eye(oracle, mode):
     """The reference's own frame: head then eye_inner parented to it (main.rs:272-273), 853x480."""
     draws = _head_scene(853, 480, rot=0.05, with_eye=True)
     o = SU.oracle_render(oracle, 853, 480, draws)
-    g = SU.gpu_render(853, 480, draws)
+    g = SU.gpu_render(853, 480, draws, mode=mode)
     SU.assert_parity(o, g)
     n_head = draws[0][0].mesh.triangles.shape[0]
     assert (g["seq"] >= n_head).any(), "no eye pixel won: the second draw was not exercised"
@@ -147,11 +155,13 @@ def test_nan_depth_degenerate_triangle(oracle):
     d, b = _synthetic_component(degenerate), _synthetic_component(big)
     sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
     for order in ((d, b), (b, d)):
-        draws = [(mc, sh) for mc in order]
-        o = SU.oracle_render(oracle, 16, 16, draws)
-        g = SU.gpu_render(16, 16, draws)
-        SU.assert_parity(o, g)
-        assert np.isnan(o["z"][0, 0]) == (order[0] is d)
+        for mode in (1, 0):
+            for W, Hh in ((16, 16), (50, 37)):
+                draws = [(mc, sh) for mc in order]
+                o = SU.oracle_render(oracle, W, Hh, draws)
+                g = SU.gpu_render(W, Hh, draws, mode=mode)
+                SU.assert_parity(o, g)
+                assert np.isnan(o["z"][0, 0]) == (order[0] is d)
 
 
 def test_offscreen_and_culled(oracle):
@@ -169,11 +179,13 @@ def test_offscreen_and_culled(oracle):
     mc = _synthetic_component(obj)
     sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
     o = SU.oracle_render(oracle, 120, 90, [(mc, sh)])
-    g = SU.gpu_render(120, 90, [(mc, sh)])
-    SU.assert_parity(o, g)
     assert o["counters"]["culled"] == 1
-    assert g["counters"]["samples"] == o["counters"]["samples"]
-    assert g["counters"]["fragments"] == o["counters"]["fragments"] < o["counters"]["samples"]
+    for mode in (1, 0):
+        g = SU.gpu_render(120, 90, [(mc, sh)], mode=mode)
+        SU.assert_parity(o, g)
+        assert g["counters"]["fragments"] == o["counters"]["fragments"] < o["counters"]["samples"]
+        if mode == 0:
+            assert g["counters"]["samples"] == o["counters"]["samples"]
 
 
 def test_empty_frame_and_empty_mesh(oracle):
@@ -188,3 +200,72 @@ def test_empty_frame_and_empty_mesh(oracle):
         assert np.isneginf(g["z"]).all() and (g["seq"] == -1).all()
         assert (g["present"] == np.array([0, 0, 0, 255], dtype=np.uint8)).all()
         assert (g["fb"] == np.array([0.0, 0.0, 0.0, 255.0])).all()
+
+
+def _random_scene(rng, n_tris, W, H, spread=1.3):
+    """Random triangle soup in NDC (identity matrices): slivers, tiny and huge triangles, shared
+    vertices, some partly off-screen -- the shapes that stress the tile raster's range pruning."""
+    from tinyrenderer_amd import helpers as H_
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    n_v = max(3, n_tris)
+    v = rng.uniform(-spread, spread, size=(n_v, 3))
+    v[:, 2] = rng.uniform(-0.9, 0.9, size=n_v)
+    # a few exact duplicates / axis-aligned edges / pixel-centre coordinates
+    v[: n_v // 8, 0] = np.round(v[: n_v // 8, 0] * 8) / 8
+    v[n_v // 8: n_v // 4, 1] = v[0, 1]
+    vt = rng.uniform(0.0, 1.0, size=(n_v, 3))
+    vn = rng.normal(size=(n_v, 3))
+    tri = np.zeros((n_tris, 9), dtype=np.uint32)
+    for k in range(n_tris):
+        scale = rng.choice([0.02, 0.1, 0.5, 3.0])
+        a = rng.integers(0, n_v)
+        near = np.argsort(np.abs(v[:, :2] - v[a, :2]).sum(axis=1))[: max(3, int(n_v * scale / 3.0))]
+        b, c = rng.choice(near, 2, replace=False)
+        tri[k] = [a, a, a, b, b, b, c, c, c]
+    obj = H_.Object(v, vt, vn, tri)
+    mc = _synthetic_component(obj, seed=int(rng.integers(1 << 30)))
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.2, -0.1, 2.0))
+    return [(mc, sh)]
+
+
+@pytest.mark.parametrize("seed,n_tris,W,H", [(1, 40, 97, 61), (2, 300, 160, 160), (3, 2000, 256, 144),
+                                              (4, 12, 641, 367), (5, 800, 48, 300)])
+def test_fuzz_random_triangles(oracle, seed, n_tris, W, H):
+    rng = np.random.default_rng(seed)
+    draws = _random_scene(rng, n_tris, W, H)
+    o = SU.oracle_render(oracle, W, H, draws)
+    for mode in (1, 0):
+        g = SU.gpu_render(W, H, draws, mode=mode)
+        info = SU.assert_parity(o, g)
+        assert g["counters"]["fragments"] == o["counters"]["fragments"]
+        assert info["f64_colour_mismatches"] == 0 and info["covered"] > 0
+
+
+def test_band_sharding_is_exact(oracle):
+    """bands of tile rows rendered by separate contexts stack to the full frame."""
+    W, Hh = 400, 300
+    draws = _head_scene(W, Hh)
+    full = SU.gpu_render(W, Hh, draws)
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    SU.assert_parity(o, full)
+    from tinyrenderer_amd import sharding
+
+    for world in (2, 3):
+        z = np.full_like(full["z"], -np.inf)
+        key = np.full_like(full["key"], np.uint64(0xFFFFFFFFFFFFFFFF))
+        present = np.zeros_like(full["present"])
+        frags = 0
+        for r in range(world):
+            y_lo, y_hi = sharding.band_rows(Hh, r, world)
+            g = SU.gpu_render(W, Hh, draws, band=(y_lo, y_hi))
+            z[:, y_lo:y_hi] = g["z"][:, y_lo:y_hi]          # reference layout is (W, H)
+            key[:, y_lo:y_hi] = g["key"][:, y_lo:y_hi]
+            present[Hh - y_hi: Hh - y_lo] = g["present"][Hh - y_hi: Hh - y_lo]  # presented rows are flipped
+            frags += g["counters"]["fragments"]
+            outside = np.ones(Hh, dtype=bool)
+            outside[y_lo:y_hi] = False
+            assert np.isneginf(g["z"][:, outside]).all()
+        assert np.array_equal(z.view(np.uint64), full["z"].view(np.uint64))
+        assert np.array_equal(key, full["key"]) and np.array_equal(present, full["present"])
+        assert frags == full["counters"]["fragments"]

@@ -24,6 +24,8 @@ TR_FLAG_TEX_OOB = 1 << 2
 TR_FLAG_NEG_INF_DEPTH = 1 << 3
 TR_FLAG_SCANLINE_OVERFLOW = 1 << 4
 TR_FLAG_NAN_PIXEL_OVERFLOW = 1 << 5
+TR_FLAG_BIN_OVERFLOW = 1 << 6
+TR_RASTER_GLOBAL, TR_RASTER_TILE = 0, 1
 TR_LAYOUT_ROW_MAJOR = 0
 TR_LAYOUT_REFERENCE = 1
 TR_OUT_RGBA8, TR_OUT_Z, TR_OUT_TRI_ID, TR_OUT_RGBA_F64 = 1, 2, 4, 8
@@ -34,7 +36,8 @@ EXPORTS = [
     "tr_texture_create", "tr_texture_destroy", "tr_draw", "tr_resolve", "tr_read_z_f64",
     "tr_read_triangle_id_u32", "tr_read_winner_key_u64", "tr_read_rgba8", "tr_read_rgba_f64",
     "tr_get_counters", "tr_get_status_flags", "tr_synchronize", "tr_get_stream",
-    "tr_device_ptr_rgba8", "tr_profile_enable", "tr_profile_read", "tr_version",
+    "tr_device_ptr_rgba8", "tr_profile_enable", "tr_profile_read", "tr_version", "tr_set_band",
+    "tr_set_raster_mode",
 ]
 
 
@@ -93,6 +96,8 @@ def load():
         "tr_profile_enable": (i32, [vp, i32]),
         "tr_profile_read": (i32, [vp, pd, C.POINTER(C.c_uint64), i32]),
         "tr_version": (C.c_char_p, []),
+        "tr_set_band": (i32, [vp, i32, i32]),
+        "tr_set_raster_mode": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

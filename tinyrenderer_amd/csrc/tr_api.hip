@@ -3,6 +3,7 @@
 // There is no CPU fallback: without a usable GPU tr_create fails with TR_ERR_NO_DEVICE.
 #include "../../include/tinyrenderer_hip.h"
 #include "tr_kernels.hip"
+#include "tr_tile.hip"
 
 #include <cmath>
 #include <cstdio>
@@ -54,9 +55,17 @@ struct tr_context {
     size_t ndc_cap = 0, nout_cap = 0;
     DrawDev* draw_table = nullptr;
     uint32_t draw_cap = 4096;
+    unsigned long long* state_blk = nullptr;     // counters | cov_counters | flags, one allocation
     unsigned long long* counters = nullptr;      // kCounterSlots x 8: [0] samples [1] fragments
     unsigned long long* cov_counters = nullptr;  // kCounterSlots x 8: [0] covered pixels
     uint32_t* flags = nullptr;
+    // tile raster (mode 1)
+    int mode = 1;                   // 1 = binned LDS tile raster (default), 0 = global-atomic raster
+    int tiles_x = 0, tiles_y = 0;
+    uint32_t* tile_cnt = nullptr;   // triangles per tile / fill cursor
+    uint32_t* tile_off = nullptr;   // n_tiles + 1
+    uint32_t* pairs = nullptr;      // tri_seq per (tile, slot)
+    uint32_t pair_cap = 0;
     NanTable* nan = nullptr;
     uint32_t tri_total = 0;
     uint32_t draw_count = 0;
@@ -196,9 +205,41 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi) {
     return TR_OK;
 }
 
+// Tile mode: the (tile, triangle) pair list has a fixed capacity; if a frame needs more, the
+// device raises bit 6, and the next host-synchronising call grows the list and redoes the resolve.
+int settle_bin_overflow(tr_context* c) {
+    if (c->mode != 1 || !c->resolved) return TR_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        uint32_t fl = 0;
+        TR_HIP(c, hipMemcpyAsync(&fl, c->flags, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+        TR_HIP(c, hipStreamSynchronize(c->stream));
+        if (!(fl & (1u << 6))) return TR_OK;
+        uint32_t need = 0;
+        TR_HIP(c, hipMemcpy(&need, c->tile_off + (size_t)c->tiles_x * c->tiles_y, sizeof(need), hipMemcpyDeviceToHost));
+        uint64_t cap = (uint64_t)need + need / 2 + 1024;
+        if (cap > 0xFFFFFFF0ull) return fail(c, TR_ERR_SIZE, "tile bin list exceeds 2^32 entries");
+        (void)hipFree(c->pairs);
+        c->pairs = nullptr;
+        TR_HIP(c, hipMalloc(&c->pairs, cap * sizeof(uint32_t)));
+        c->pair_cap = (uint32_t)cap;
+        fl &= ~(1u << 6);
+        TR_HIP(c, hipMemcpy(c->flags, &fl, sizeof(fl), hipMemcpyHostToDevice));
+        uint32_t mask = c->resolved_mask;
+        c->resolved = false;
+        // the fragment counter was bumped by the aborted attempt
+        TR_HIP(c, hipMemsetAsync(c->counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
+        int rc = tr_resolve(c, mask);
+        if (rc != TR_OK) return rc;
+    }
+    return fail(c, TR_ERR_UNSUPPORTED, "tile bin list kept overflowing");
+}
+
 int need_plane(tr_context* c, uint32_t plane) {
-    if (c->resolved && (c->resolved_mask & plane)) return TR_OK;
-    return tr_resolve(c, (c->resolved ? c->resolved_mask : 0u) | plane);
+    if (!(c->resolved && (c->resolved_mask & plane))) {
+        int rc = tr_resolve(c, (c->resolved ? c->resolved_mask : 0u) | plane);
+        if (rc != TR_OK) return rc;
+    }
+    return settle_bin_overflow(c);
 }
 
 template <typename T>
@@ -225,7 +266,7 @@ int read_plane(tr_context* c, const T* dev, T* out, int layout, int comps) {
 
 extern "C" {
 
-const char* tr_version(void) { return "tinyrenderer_hip abi=1 arch=gfx950 fp=f64 contract=off"; }
+const char* tr_version(void) { return "tinyrenderer_hip abi=2 arch=gfx950 fp=f64 contract=off"; }
 
 const char* tr_last_error(const tr_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -243,6 +284,7 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     c->H = height;
     c->y_lo = 0;
     c->y_hi = height;
+    if (const char* e = std::getenv("TR_RASTER_MODE")) c->mode = (std::strcmp(e, "global") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     auto bail = [&](int code) {
@@ -264,9 +306,19 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     c->wkey = c->planes + npix;
     if (hipMalloc(&c->rgba8, npix * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMalloc(&c->draw_table, c->draw_cap * sizeof(DrawDev)) != hipSuccess) return bail(TR_ERR_OOM);
-    if (hipMalloc(&c->counters, kCounterSlots * 8 * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
-    if (hipMalloc(&c->cov_counters, kCounterSlots * 8 * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
-    if (hipMalloc(&c->flags, sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->state_blk, (2 * kCounterSlots * 8 + 8) * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
+    c->counters = c->state_blk;
+    c->cov_counters = c->state_blk + kCounterSlots * 8;
+    c->flags = (uint32_t*)(c->state_blk + 2 * kCounterSlots * 8);
+    c->tiles_x = (width + kTile - 1) / kTile;
+    c->tiles_y = (height + kTile - 1) / kTile;
+    {
+        size_t n_tiles = (size_t)c->tiles_x * c->tiles_y;
+        c->pair_cap = 4u << 20;
+        if (hipMalloc(&c->tile_cnt, n_tiles * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->tile_off, (n_tiles + 1) * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+    }
     if (hipMalloc(&c->nan, sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(TR_ERR_HIP);
     if (ensure_tri_capacity(c, 16384) != TR_OK) return bail(TR_ERR_OOM);
@@ -284,7 +336,8 @@ void tr_destroy(tr_context* c) {
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
     (void)hipFree(c->half_off); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
-    (void)hipFree(c->draw_table); (void)hipFree(c->counters); (void)hipFree(c->cov_counters); (void)hipFree(c->flags); (void)hipFree(c->nan);
+    (void)hipFree(c->draw_table); (void)hipFree(c->state_blk); (void)hipFree(c->nan);
+    (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->pairs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -296,11 +349,17 @@ int tr_clear(tr_context* c) {
     TR_HIP(c, hipSetDevice(c->device));
     ProfScope ps(c, ST_CLEAR);
     size_t npix = (size_t)c->W * c->H;
-    // depth = "no sample yet", winner = none: both all-ones.
-    TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * npix * sizeof(unsigned long long), c->stream));
-    TR_HIP(c, hipMemsetAsync(c->counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(k_reset_frame, dim3(1), dim3(64), 0, c->stream, c->flags, c->nan, c->half_off);
-    TR_HIP(c, hipGetLastError());
+    // counters, covered-pixel counters and status flags in one memset
+    TR_HIP(c, hipMemsetAsync(c->state_blk, 0, (2 * kCounterSlots * 8 + 8) * sizeof(unsigned long long), c->stream));
+    if (c->mode == 1) {
+        // tile raster: no plane is cleared; every non-empty tile is rewritten, empty ones are never read
+        TR_HIP(c, hipMemsetAsync(c->tile_cnt, 0, (size_t)c->tiles_x * c->tiles_y * sizeof(uint32_t), c->stream));
+    } else {
+        // depth = "no sample yet", winner = none: both all-ones.
+        TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * npix * sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_reset_frame, dim3(1), dim3(64), 0, c->stream, c->flags, c->nan, c->half_off);
+        TR_HIP(c, hipGetLastError());
+    }
     c->tri_total = 0;
     c->draw_count = 0;
     c->resolved = false;
@@ -440,6 +499,8 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
         sa.vpm = host_mat4_mul(sc, trn);
         sa.nmat = nmat;
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
+        sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+        sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;
         DrawDev& d = sa.params;
         std::memset(&d, 0, sizeof(d));
         d.tex = p->diffuse ? p->diffuse->dev : nullptr;
@@ -461,23 +522,25 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
         sa.draw_table = c->draw_table;
         hipLaunchKernelGGL(k_setup, dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
-        // prefix of scanline counts, continuing from the previous draw's total
-        const uint32_t lo = 2u * tri_base;
-        uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
-        if (tiles == 1) {
-            hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
-                               c->half_off + lo, (const unsigned long long*)nullptr, c->flags);
-        } else {
-            hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo,
-                               n_halves, c->tile_sum);
-            hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(kScanThreads), 0, c->stream, c->tile_sum, tiles,
-                               c->half_off + lo, c->flags);
-            hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
-                               c->half_off + lo, (const unsigned long long*)c->tile_sum, c->flags);
+        if (c->mode == 0) {
+            // prefix of scanline counts, continuing from the previous draw's total
+            const uint32_t lo = 2u * tri_base;
+            uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
+            if (tiles == 1) {
+                hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
+                                   c->half_off + lo, (const unsigned long long*)nullptr, c->flags);
+            } else {
+                hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo,
+                                   n_halves, c->tile_sum);
+                hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(kScanThreads), 0, c->stream, c->tile_sum, tiles,
+                                   c->half_off + lo, c->flags);
+                hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
+                                   c->half_off + lo, (const unsigned long long*)c->tile_sum, c->flags);
+            }
+            TR_HIP(c, hipGetLastError());
         }
-        TR_HIP(c, hipGetLastError());
     }
-    {
+    if (c->mode == 0) {
         ProfScope ps(c, ST_DEPTH);
         rc = launch_raster(c, 0, 2u * tri_base, 2u * tri_base + n_halves);
         if (rc != TR_OK) return rc;
@@ -495,19 +558,47 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
     if ((out_mask & TR_OUT_Z) && !c->z_out) TR_HIP(c, hipMalloc(&c->z_out, npix * sizeof(double)));
     if ((out_mask & TR_OUT_TRI_ID) && !c->tri_out) TR_HIP(c, hipMalloc(&c->tri_out, npix * sizeof(uint32_t)));
     if ((out_mask & TR_OUT_RGBA_F64) && !c->rgba_f64) TR_HIP(c, hipMalloc(&c->rgba_f64, npix * 4 * sizeof(double)));
-    if (!c->resolved && c->tri_total) {
+    if (!c->resolved && c->tri_total && c->mode == 0) {
         ProfScope ps(c, ST_WINNER);
         int rc = launch_raster(c, 1, 0u, 2u * c->tri_total);
         if (rc != TR_OK) return rc;
     }
+    if (!c->resolved && c->mode == 1) {
+        const uint32_t n_tiles = (uint32_t)(c->tiles_x * c->tiles_y);
+        {
+            ProfScope ps(c, ST_DEPTH);  // stage slot 3 = binning in tile mode
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileScanThreads), 0, c->stream, c->tile_cnt, c->tile_off,
+                               n_tiles, c->pair_cap, c->flags);
+            if (c->tri_total)
+                hipLaunchKernelGGL(k_bin_fill, dim3((c->tri_total + 255) / 256), dim3(256), 0, c->stream, c->rast,
+                                   c->tri_total, c->tile_off, c->tile_cnt, c->pairs, c->pair_cap, c->tiles_x, c->y_lo,
+                                   c->y_hi);
+            TR_HIP(c, hipGetLastError());
+        }
+        if (c->tri_total) {
+            ProfScope ps(c, ST_WINNER);  // stage slot 4 = tile raster in tile mode
+            TileArgs ta;
+            ta.tile_off = c->tile_off; ta.pairs = c->pairs; ta.pair_cap = c->pair_cap; ta.rast = c->rast;
+            ta.wkey = c->wkey; ta.W = c->W; ta.H = c->H; ta.tiles_x = c->tiles_x;
+            ta.ty_lo = c->y_lo / kTile; ta.y_lo = c->y_lo; ta.y_hi = c->y_hi;
+            ta.counters = c->counters; ta.flags = c->flags;
+            int band_rows = (c->y_hi - 1) / kTile - ta.ty_lo + 1;
+            hipLaunchKernelGGL(k_tile_raster, dim3(c->tiles_x, band_rows), dim3(64), 0, c->stream, ta);
+            TR_HIP(c, hipGetLastError());
+        }
+    }
     {
         ProfScope ps(c, ST_SHADE);
         ShadeArgs sa;
-        sa.wkey = c->wkey; sa.rast = c->rast; sa.shade = c->shade; sa.draws = c->draw_table; sa.nan = c->nan;
+        sa.wkey = c->wkey; sa.rast = c->rast; sa.shade = c->shade; sa.draws = c->draw_table;
+        sa.nan = c->mode == 0 ? c->nan : nullptr;
+        sa.tile_off = c->mode == 1 ? c->tile_off : nullptr;
+        sa.tiles_x = c->tiles_x;
         sa.W = c->W; sa.H = c->H; sa.out_mask = out_mask; sa.rgba8 = c->rgba8; sa.z_out = c->z_out;
         sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.cov_counters = c->cov_counters;
         TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(k_shade, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, c->stream, sa);
+        hipLaunchKernelGGL(k_shade, dim3((c->W + kShadeBW - 1) / kShadeBW, (c->H + kShadeBH - 1) / kShadeBH), dim3(256),
+                           0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }
     c->resolved = true;
@@ -535,6 +626,18 @@ int tr_read_winner_key_u64(tr_context* c, uint64_t* out, int layout) {
     if (rc != TR_OK) return rc;
     rc = read_plane<uint64_t>(c, (const uint64_t*)c->wkey, out, layout, 1);
     if (rc != TR_OK) return rc;
+    if (c->mode == 1) {  // tiles with an empty list hold no keys in the plane
+        size_t n_tiles = (size_t)c->tiles_x * c->tiles_y;
+        std::vector<uint32_t> off(n_tiles + 1);
+        TR_HIP(c, hipMemcpy(off.data(), c->tile_off, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int y = 0; y < c->H; ++y)
+            for (int x = 0; x < c->W; ++x) {
+                size_t t = (size_t)(y / kTile) * c->tiles_x + (x / kTile);
+                if (off[t + 1] <= off[t] || !c->tri_total)
+                    out[layout == TR_LAYOUT_ROW_MAJOR ? (size_t)y * c->W + x : (size_t)x * c->H + y] = kKeyNone;
+            }
+        return TR_OK;
+    }
     NanTable nt;
     TR_HIP(c, hipMemcpy(&nt, c->nan, sizeof(nt), hipMemcpyDeviceToHost));
     for (uint32_t s = 0; s < kNanSlots; ++s)
@@ -573,6 +676,10 @@ int tr_read_rgba_f64(tr_context* c, double* out, int layout) {
 int tr_get_counters(tr_context* c, uint64_t out[8]) {
     if (!c || !out) return TR_ERR_INVALID;
     TR_HIP(c, hipSetDevice(c->device));
+    {
+        int rc = settle_bin_overflow(c);
+        if (rc != TR_OK) return rc;
+    }
     std::vector<unsigned long long> tmp(kCounterSlots * 8), cov(kCounterSlots * 8);
     TR_HIP(c, hipMemcpyAsync(tmp.data(), c->counters, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     TR_HIP(c, hipMemcpyAsync(cov.data(), c->cov_counters, cov.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -587,7 +694,7 @@ int tr_get_counters(tr_context* c, uint64_t out[8]) {
         out[4] += cov[s * 8];
     }
     if (!c->resolved) out[4] = 0;
-    out[2] = total_scan;
+    out[2] = c->mode == 0 ? total_scan : 0;  // scanlines / samples are only counted by the global raster
     out[3] = c->tri_total;
     return TR_OK;
 }
@@ -595,6 +702,10 @@ int tr_get_counters(tr_context* c, uint64_t out[8]) {
 int tr_get_status_flags(tr_context* c, uint32_t* out_flags) {
     if (!c || !out_flags) return TR_ERR_INVALID;
     TR_HIP(c, hipSetDevice(c->device));
+    {
+        int rc = settle_bin_overflow(c);
+        if (rc != TR_OK) return rc;
+    }
     TR_HIP(c, hipMemcpyAsync(out_flags, c->flags, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TR_HIP(c, hipStreamSynchronize(c->stream));
     return TR_OK;
@@ -616,6 +727,26 @@ int tr_get_stream(tr_context* c, void** out_hip_stream) {
 int tr_device_ptr_rgba8(tr_context* c, void** out_dev_ptr) {
     if (!c || !out_dev_ptr) return TR_ERR_INVALID;
     *out_dev_ptr = (void*)c->rgba8;
+    return TR_OK;
+}
+
+int tr_set_band(tr_context* c, int y_lo, int y_hi) {
+    if (!c) return TR_ERR_INVALID;
+    if (y_lo < 0 || y_hi > c->H || y_lo >= y_hi || (y_lo % kTile) != 0 || (y_hi != c->H && (y_hi % kTile) != 0))
+        return fail(c, TR_ERR_INVALID, "band must be whole 16-pixel tile rows inside the frame");
+    if (c->tri_total) return fail(c, TR_ERR_INVALID, "tr_set_band must follow tr_clear, before any draw");
+    c->y_lo = y_lo;
+    c->y_hi = y_hi;
+    return TR_OK;
+}
+
+int tr_set_raster_mode(tr_context* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) return TR_ERR_INVALID;
+    if (c->tri_total) return fail(c, TR_ERR_INVALID, "tr_set_raster_mode must follow tr_clear, before any draw");
+    if (mode != c->mode) {
+        c->mode = mode;
+        return tr_clear(c);  // the two modes clear different state
+    }
     return TR_OK;
 }
 

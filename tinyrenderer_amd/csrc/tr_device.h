@@ -29,8 +29,13 @@ struct Mat4 {  // column-major, m[c*4+r] (nalgebra storage order)
 struct __attribute__((aligned(128))) TriRaster {
     double s0[3], s1[3], s2[3], sp[3];
     uint32_t res[2];  // resolution of half 0 / half 1 (mod.rs:363-369); 0 = no scanlines
-    uint32_t pad[6];
+    uint16_t tx0, ty0, tx1, ty1;  // inclusive rect of 16x16 tiles its samples can touch (tx0 > tx1: none)
+    uint32_t flags;               // kTriNonFinite: x/y of a point is NaN/inf, no range pruning
+    uint32_t pad[3];
 };
+constexpr uint32_t kTriNonFinite = 1u;
+constexpr int kTile = 16;             // screen tile edge in pixels
+constexpr double kPruneMargin = 1.0 / 64.0;  // slack (pixels) of every conservative range test
 static_assert(sizeof(TriRaster) == 128, "TriRaster must be 128 B");
 
 // Per-triangle record read by the shade pass only (mod.rs:329,333-358,477-535).

@@ -51,7 +51,11 @@ struct SetupArgs {
     Mat4 nmat;             // for the face-normal fallback
     TriRaster* rast;
     TriShade* shade;
-    uint32_t* half_cnt;    // scanlines per half, 2 per triangle
+    uint32_t* half_cnt;    // scanlines per half, 2 per triangle (global-atomic raster only)
+    uint32_t* tile_cnt;    // triangles per tile (tile raster only)
+    int tiles_x, tiles_y;
+    int y_lo, y_hi;        // band of pixel rows owned by this context
+    int mode;              // bit0: fill half_cnt, bit1: count tiles
     uint32_t* flags;
     DrawDev params;
     DrawDev* draw_table;
@@ -85,6 +89,9 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     }
     TriRaster R;
     TriShade S;
+    R.res[0] = R.res[1] = 0;
+    R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0;
+    if (cull) a.rast[seq] = R;  // the binning pass reads res / rect of every triangle
     if (!cull) {
         // mod.rs:320-327 viewport transform; w of the product is 1 unless inputs are non-finite.
         double vx[3], vy[3], vz[3];
@@ -221,11 +228,51 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
         S.flags = fl;
         R.res[0] = res0;
         R.res[1] = res1;
+        // ---- conservative rect of tiles the triangle's samples can land in: every sample lies
+        // in the hull of S0,S1,S2,split up to a few ulp; a sample at x lands in column round(x).
+        R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0;
+        if (res0) {
+            double xs[4] = {R.s0[0], R.s1[0], R.s2[0], R.sp[0]};
+            double ys[4] = {R.s0[1], R.s1[1], R.s2[1], R.sp[1]};
+            bool finite = true;
+            double xmin = xs[0], xmax = xs[0], ymin = ys[0], ymax = ys[0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                finite = finite && fabs(xs[q]) < __builtin_huge_val() && fabs(ys[q]) < __builtin_huge_val();
+                xmin = fmin(xmin, xs[q]); xmax = fmax(xmax, xs[q]);
+                ymin = fmin(ymin, ys[q]); ymax = fmax(ymax, ys[q]);
+            }
+            if (!finite) {
+                R.flags = kTriNonFinite;  // samples with a NaN coordinate land in column 0 / row 0
+            } else {
+                double cl = fmax(ceil(xmin - kPruneMargin - 0.5), 0.0);
+                double ch = fmin(floor(xmax + kPruneMargin + 0.5), (double)(a.W - 1));
+                double rl = fmax(ceil(ymin - kPruneMargin - 0.5), (double)a.y_lo);
+                double rh = fmin(floor(ymax + kPruneMargin + 0.5), (double)(a.y_hi - 1));
+                if (cl <= ch && rl <= rh) {
+                    R.tx0 = (uint16_t)((int)cl / kTile); R.tx1 = (uint16_t)((int)ch / kTile);
+                    R.ty0 = (uint16_t)((int)rl / kTile); R.ty1 = (uint16_t)((int)rh / kTile);
+                }
+            }
+        }
         a.rast[seq] = R;
         a.shade[seq] = S;
+        if ((a.mode & 2) && res0) {
+            if (R.flags & kTriNonFinite) {
+                int ty_lo = a.y_lo / kTile, ty_hi = (a.y_hi - 1) / kTile;
+                if (ty_lo == 0)
+                    for (int tx = 0; tx < a.tiles_x; ++tx) atomicAdd(&a.tile_cnt[tx], 1u);
+                for (int ty = (ty_lo > 1 ? ty_lo : 1); ty <= ty_hi; ++ty) atomicAdd(&a.tile_cnt[ty * a.tiles_x], 1u);
+            } else {
+                for (int ty = R.ty0; ty <= R.ty1; ++ty)
+                    for (int tx = R.tx0; tx <= R.tx1; ++tx) atomicAdd(&a.tile_cnt[ty * a.tiles_x + tx], 1u);
+            }
+        }
     }
-    a.half_cnt[2 * (size_t)seq] = res0 ? res0 + 1u : 0u;
-    a.half_cnt[2 * (size_t)seq + 1] = res1 ? res1 + 1u : 0u;
+    if (a.mode & 1) {
+        a.half_cnt[2 * (size_t)seq] = res0 ? res0 + 1u : 0u;
+        a.half_cnt[2 * (size_t)seq + 1] = res1 ? res1 + 1u : 0u;
+    }
 }
 
 // ================================================================= (2b) scan
@@ -498,7 +545,9 @@ struct ShadeArgs {
     const TriRaster* rast;
     const TriShade* shade;
     const DrawDev* draws;
-    const NanTable* nan;
+    const NanTable* nan;        // global-atomic raster only (nullptr in tile mode)
+    const uint32_t* tile_off;   // tile mode: a tile with an empty list has no keys in wkey
+    int tiles_x;
     int W, H;
     uint32_t out_mask;
     uint32_t* rgba8;    // row-major, packed r | g<<8 | b<<16 | a<<24
@@ -551,24 +600,27 @@ __device__ __forceinline__ uint32_t f64_as_u8(double v) {
     return (uint32_t)v;
 }
 
+constexpr int kShadeBW = 32, kShadeBH = 8;  // pixels per 256-thread block: rows of 128 B of RGBA8
+
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
-    uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t npix = (uint32_t)a.W * (uint32_t)a.H;
-    bool live = pix < npix;
-    unsigned long long key = live ? a.wkey[pix] : kKeyNone;
-    bool nan_win = false;
-    if (a.nan->pix[0] != kNanEmpty && live) {
-        for (uint32_t s = 0; s < kNanSlots; ++s)
-            if (a.nan->pix[s] == pix && a.nan->first_nan[s] < a.nan->first_any[s]) {
-                key = a.nan->first_nan[s];
-                nan_win = true;
-            }
+    const int x = blockIdx.x * kShadeBW + (threadIdx.x & (kShadeBW - 1));
+    const int y = blockIdx.y * kShadeBH + (threadIdx.x / kShadeBW);
+    const bool live = x < a.W && y < a.H;
+    const uint32_t pix = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+    bool listed = live;
+    if (a.tile_off && live) {
+        int tile = (y / kTile) * a.tiles_x + (x / kTile);
+        listed = a.tile_off[tile + 1] > a.tile_off[tile];
     }
-    (void)nan_win;
+    unsigned long long key = listed ? a.wkey[pix] : kKeyNone;
+    if (a.nan && live && a.nan->pix[0] != kNanEmpty) {
+        for (uint32_t s = 0; s < kNanSlots; ++s)
+            if (a.nan->pix[s] == pix && a.nan->first_nan[s] < a.nan->first_any[s]) key = a.nan->first_nan[s];
+    }
     bool has = key != kKeyNone;
     unsigned long long nwin = __popcll(__ballot(has));
     if ((threadIdx.x & 63) == 0 && nwin)
-        atomicAdd(&a.cov_counters[(size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8], nwin);
+        atomicAdd(&a.cov_counters[(size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8], nwin);
     if (!live) return;
     double col[4] = {0.0, 0.0, 0.0, 255.0};  // BLACK, helpers/mod.rs:22
     double zval = -__builtin_huge_val();

@@ -115,7 +115,7 @@ class ModelRendererState:
     """src/model_renderer/mod.rs:29-35,150-173.  `frame_buffer` / `z_buffer` are read back from
     the GPU on access, in the reference's (W, H, C) layout."""
 
-    def __init__(self, frame_width, frame_height, device=0):
+    def __init__(self, frame_width, frame_height, device=0, raster_mode=None):
         self._lib = _ffi.load()
         self.frame_width = int(frame_width)
         self.frame_height = int(frame_height)
@@ -125,6 +125,8 @@ class ModelRendererState:
             raise _ffi.TrError(
                 f"tr_create failed: {_ffi.TR_ERR.get(rc, rc)} (a gfx950 GPU is required; there is no CPU fallback)")
         self._ctx = ctx
+        if raster_mode is not None:
+            _ffi.check(ctx, self._lib.tr_set_raster_mode(ctx, int(raster_mode)), "tr_set_raster_mode")
         self._meshes = {}
         self._textures = {}
         self._keepalive = []
@@ -191,6 +193,11 @@ class ModelRendererState:
         out = np.empty((self.frame_height, self.frame_width, 4), dtype=np.uint8)
         _ffi.check(self._ctx, self._lib.tr_read_rgba8(self._ctx, out.ctypes.data, 1), "tr_read_rgba8")
         return out
+
+    def set_band(self, y_lo, y_hi):
+        """Restrict this context to pixel rows [y_lo, y_hi) (whole 16-pixel tile rows); call after
+        clear_screen and before the first draw."""
+        _ffi.check(self._ctx, self._lib.tr_set_band(self._ctx, int(y_lo), int(y_hi)), "tr_set_band")
 
     def resolve(self, out_mask=_ffi.TR_OUT_RGBA8):
         _ffi.check(self._ctx, self._lib.tr_resolve(self._ctx, out_mask), "tr_resolve")
