@@ -63,9 +63,11 @@ struct tr_context {
     int mode = 1;                   // 1 = binned LDS tile raster (default), 0 = global-atomic raster
     int tiles_x = 0, tiles_y = 0;
     uint32_t* tile_cnt = nullptr;   // triangles per tile / fill cursor
-    uint32_t* tile_off = nullptr;   // n_tiles + 1
+    uint32_t* tile_off = nullptr;   // n_tiles_padded + 4: offsets, total, number of non-empty tiles
+    uint32_t* tile_list = nullptr;  // ids of non-empty tiles
     uint32_t* pairs = nullptr;      // tri_seq per (tile, slot)
     uint32_t pair_cap = 0;
+    uint32_t n_tiles_padded = 0;    // tile arrays are padded to a multiple of 4*kTileScanThreads
     NanTable* nan = nullptr;
     uint32_t tri_total = 0;
     uint32_t draw_count = 0;
@@ -314,9 +316,12 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     c->tiles_y = (height + kTile - 1) / kTile;
     {
         size_t n_tiles = (size_t)c->tiles_x * c->tiles_y;
+        const size_t quantum = 4 * (size_t)kTileScanThreads;
+        c->n_tiles_padded = (uint32_t)((n_tiles + quantum - 1) / quantum * quantum);
         c->pair_cap = 4u << 20;
-        if (hipMalloc(&c->tile_cnt, n_tiles * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
-        if (hipMalloc(&c->tile_off, (n_tiles + 1) * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->tile_cnt, c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->tile_off, ((size_t)c->n_tiles_padded + 4) * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->tile_list, (size_t)c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     }
     if (hipMalloc(&c->nan, sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
@@ -337,7 +342,7 @@ void tr_destroy(tr_context* c) {
     (void)hipFree(c->rgba_f64); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
     (void)hipFree(c->half_off); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->state_blk); (void)hipFree(c->nan);
-    (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->pairs);
+    (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -353,7 +358,7 @@ int tr_clear(tr_context* c) {
     TR_HIP(c, hipMemsetAsync(c->state_blk, 0, (2 * kCounterSlots * 8 + 8) * sizeof(unsigned long long), c->stream));
     if (c->mode == 1) {
         // tile raster: no plane is cleared; every non-empty tile is rewritten, empty ones are never read
-        TR_HIP(c, hipMemsetAsync(c->tile_cnt, 0, (size_t)c->tiles_x * c->tiles_y * sizeof(uint32_t), c->stream));
+        TR_HIP(c, hipMemsetAsync(c->tile_cnt, 0, (size_t)c->n_tiles_padded * sizeof(uint32_t), c->stream));
     } else {
         // depth = "no sample yet", winner = none: both all-ones.
         TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * npix * sizeof(unsigned long long), c->stream));
@@ -568,9 +573,9 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         {
             ProfScope ps(c, ST_DEPTH);  // stage slot 3 = binning in tile mode
             hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileScanThreads), 0, c->stream, c->tile_cnt, c->tile_off,
-                               n_tiles, c->pair_cap, c->flags);
+                               c->tile_list, n_tiles, c->n_tiles_padded, c->pair_cap, c->flags);
             if (c->tri_total)
-                hipLaunchKernelGGL(k_bin_fill, dim3((c->tri_total + 255) / 256), dim3(256), 0, c->stream, c->rast,
+                hipLaunchKernelGGL(k_bin_fill, dim3((c->tri_total * kFillLanes + 255) / 256), dim3(256), 0, c->stream, c->rast,
                                    c->tri_total, c->tile_off, c->tile_cnt, c->pairs, c->pair_cap, c->tiles_x, c->y_lo,
                                    c->y_hi);
             TR_HIP(c, hipGetLastError());
@@ -578,12 +583,26 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         if (c->tri_total) {
             ProfScope ps(c, ST_WINNER);  // stage slot 4 = tile raster in tile mode
             TileArgs ta;
+            ta.tile_list = c->tile_list; ta.n_padded = c->n_tiles_padded;
             ta.tile_off = c->tile_off; ta.pairs = c->pairs; ta.pair_cap = c->pair_cap; ta.rast = c->rast;
             ta.wkey = c->wkey; ta.W = c->W; ta.H = c->H; ta.tiles_x = c->tiles_x;
-            ta.ty_lo = c->y_lo / kTile; ta.y_lo = c->y_lo; ta.y_hi = c->y_hi;
+            ta.y_lo = c->y_lo; ta.y_hi = c->y_hi;
             ta.counters = c->counters; ta.flags = c->flags;
-            int band_rows = (c->y_hi - 1) / kTile - ta.ty_lo + 1;
-            hipLaunchKernelGGL(k_tile_raster, dim3(c->tiles_x, band_rows), dim3(64), 0, c->stream, ta);
+            ta.debug = 0;
+            if (const char* e = std::getenv("TR_TILE_DEBUG")) ta.debug = std::atoi(e);
+            int grid = kTileGrid;
+            if (const char* e = std::getenv("TR_TILE_GRID")) grid = std::atoi(e);
+            static bool printed = false;
+            if (ta.debug && !printed) {
+                printed = true;
+                int nb = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile_raster, kTileThreads, 0);
+                hipFuncAttributes fa;
+                (void)hipFuncGetAttributes(&fa, (const void*)k_tile_raster);
+                std::fprintf(stderr, "k_tile_raster: occupancy %d blocks/CU, regs %d, lds %zu, grid %d\n", nb, fa.numRegs,
+                             fa.sharedSizeBytes, grid);
+            }
+            hipLaunchKernelGGL(k_tile_raster, dim3(grid), dim3(kTileThreads), 0, c->stream, ta);
             TR_HIP(c, hipGetLastError());
         }
     }
@@ -691,11 +710,18 @@ int tr_get_counters(tr_context* c, uint64_t out[8]) {
     for (uint32_t s = 0; s < kCounterSlots; ++s) {
         out[0] += tmp[s * 8];
         out[1] += tmp[s * 8 + 1];
+        out[5] += tmp[s * 8 + 5];
+        out[6] += tmp[s * 8 + 6];
+        out[7] += tmp[s * 8 + 7];
         out[4] += cov[s * 8];
     }
     if (!c->resolved) out[4] = 0;
     out[2] = c->mode == 0 ? total_scan : 0;  // scanlines / samples are only counted by the global raster
     out[3] = c->tri_total;
+    if (std::getenv("TR_TILE_DEBUG") && std::atoi(std::getenv("TR_TILE_DEBUG")) == 8) {
+        out[2] = tmp[2];
+        out[3] = tmp[3];
+    }
     return TR_OK;
 }
 

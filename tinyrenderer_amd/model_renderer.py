@@ -208,7 +208,8 @@ class ModelRendererState:
     def counters(self):
         out = (C.c_uint64 * 8)()
         _ffi.check(self._ctx, self._lib.tr_get_counters(self._ctx, out), "tr_get_counters")
-        names = ["samples", "fragments", "scanlines", "triangles", "covered_pixels"]
+        names = ["samples", "fragments", "scanlines", "triangles", "covered_pixels", "tile_sample_evals",
+                 "tile_segments", "tile_lane_steps"]
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def status_flags(self):
