@@ -61,8 +61,9 @@ enum {
 
 /* Raster strategies (same results, bit for bit). */
 enum {
-    TR_RASTER_GLOBAL = 0, /* samples enumerated frame-wide, 64-bit atomicMin on HBM planes */
-    TR_RASTER_TILE = 1    /* default: triangles binned to 16x16 tiles, depth/winner tiles in LDS */
+    TR_RASTER_GLOBAL = 0, /* default: samples enumerated frame-wide, 64-bit atomicMin on HBM planes */
+    TR_RASTER_TILE = 1    /* triangles binned to 16x16 tiles, depth/winner tiles in LDS;
+                             env TR_RASTER_MODE=tile selects it at tr_create */
 };
 
 /* Buffer layouts for the tr_read_* calls. */

@@ -60,7 +60,7 @@ struct tr_context {
     unsigned long long* cov_counters = nullptr;  // kCounterSlots x 8: [0] covered pixels
     uint32_t* flags = nullptr;
     // tile raster (mode 1)
-    int mode = 1;                   // 1 = binned LDS tile raster (default), 0 = global-atomic raster
+    int mode = 0;                   // 0 = global-atomic raster (default: faster on MI355X so far), 1 = binned LDS tile raster
     int tiles_x = 0, tiles_y = 0;
     uint32_t* tile_cnt = nullptr;   // triangles per tile / fill cursor
     uint32_t* tile_off = nullptr;   // n_tiles_padded + 4: offsets, total, number of non-empty tiles
@@ -286,7 +286,7 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     c->H = height;
     c->y_lo = 0;
     c->y_hi = height;
-    if (const char* e = std::getenv("TR_RASTER_MODE")) c->mode = (std::strcmp(e, "global") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
+    if (const char* e = std::getenv("TR_RASTER_MODE")) c->mode = (std::strcmp(e, "tile") == 0 || std::strcmp(e, "1") == 0) ? 1 : 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     auto bail = [&](int code) {
