@@ -120,8 +120,11 @@ int tr_draw(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params);
 
 /* No reference analogue (the reference shades inside the z-test): selects the winning sample per
  * pixel over all draws since tr_clear and runs the deferred shade.  out_mask selects which
- * planes are written besides RGBA8 (TR_OUT_*). */
-enum { TR_OUT_RGBA8 = 1, TR_OUT_Z = 2, TR_OUT_TRI_ID = 4, TR_OUT_RGBA_F64 = 8 };
+ * planes are written besides RGBA8 (TR_OUT_*).  With TR_OUT_RGBA8 alone (the fast path) the
+ * global raster's depth / winner planes are wiped as they are consumed, which makes the next
+ * tr_clear free; asking for another plane later re-runs the raster passes from the recorded
+ * draws. */
+enum { TR_OUT_RGBA8 = 1, TR_OUT_Z = 2, TR_OUT_TRI_ID = 4, TR_OUT_RGBA_F64 = 8, TR_OUT_KEY = 16 };
 int tr_resolve(tr_context* ctx, uint32_t out_mask);
 
 /* Replace reads of state.z_buffer.nd_img / state.frame_buffer.nd_img

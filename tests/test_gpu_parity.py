@@ -269,3 +269,38 @@ def test_band_sharding_is_exact(oracle):
         assert np.array_equal(z.view(np.uint64), full["z"].view(np.uint64))
         assert np.array_equal(key, full["key"]) and np.array_equal(present, full["present"])
         assert frags == full["counters"]["fragments"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_frame_reuse_and_late_plane_requests(oracle, mode):
+    """One context over several frames: the RGBA8-only resolve wipes the global raster's planes
+    (free clear), a later request for z / keys re-runs the passes, draws after a resolve extend
+    the frame, and a clear really clears."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 320, 200
+    draws = _head_scene(W, Hh, with_eye=True)
+    o2 = SU.oracle_render(oracle, W, Hh, draws)
+    o1 = SU.oracle_render(oracle, W, Hh, draws[:1])
+    st = ModelRendererState(W, Hh, raster_mode=mode)
+    try:
+        for _ in range(2):
+            clear_screen(st)
+            render_mesh_component(st, *draws[0])
+            st.resolve(_ffi.TR_OUT_RGBA8)                      # fast path
+            assert np.array_equal(st.present(), o1["present"])
+            z = st.z_buffer[..., 0]                            # late request for another plane
+            assert np.array_equal(z.view(np.uint64), o1["z"].view(np.uint64))
+            assert np.array_equal(st.winner_keys(), o1["key"])
+            render_mesh_component(st, *draws[1])               # extend the same frame
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            assert np.array_equal(st.present(), o2["present"])
+            assert np.array_equal(st.winner_keys(), o2["key"])
+            assert np.array_equal(st.z_buffer[..., 0].view(np.uint64), o2["z"].view(np.uint64))
+        clear_screen(st)
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        assert (st.present() == np.array([0, 0, 0, 255], dtype=np.uint8)).all()
+        assert np.isneginf(st.z_buffer).all()
+    finally:
+        st.close()

@@ -28,7 +28,7 @@ TR_FLAG_BIN_OVERFLOW = 1 << 6
 TR_RASTER_GLOBAL, TR_RASTER_TILE = 0, 1
 TR_LAYOUT_ROW_MAJOR = 0
 TR_LAYOUT_REFERENCE = 1
-TR_OUT_RGBA8, TR_OUT_Z, TR_OUT_TRI_ID, TR_OUT_RGBA_F64 = 1, 2, 4, 8
+TR_OUT_RGBA8, TR_OUT_Z, TR_OUT_TRI_ID, TR_OUT_RGBA_F64, TR_OUT_KEY = 1, 2, 4, 8, 16
 
 # Every symbol include/tinyrenderer_hip.h declares (checked by tests/test_abi.py).
 EXPORTS = [

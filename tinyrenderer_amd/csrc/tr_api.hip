@@ -43,6 +43,13 @@ struct tr_context {
     double* z_out = nullptr;
     uint32_t* tri_out = nullptr;
     double* rgba_f64 = nullptr;
+    unsigned long long* key_out = nullptr;
+    // global raster: what the depth / winner planes currently hold
+    bool planes_clean = false;      // every entry is "none"
+    uint32_t depth_upto = 0;        // triangles whose depth pass is reflected in the depth plane
+    bool keys_valid = false;        // winner pass done for all of them
+    bool wkey_dirty = false;        // winner plane holds keys of an earlier winner pass
+    bool cov_dirty = false;         // covered-pixel counters hold a previous resolve of this frame
     TriRaster* rast = nullptr;
     TriShade* shade = nullptr;
     uint32_t* half_cnt = nullptr;
@@ -339,7 +346,7 @@ void tr_destroy(tr_context* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
-    (void)hipFree(c->rgba_f64); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
+    (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
     (void)hipFree(c->half_off); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->state_blk); (void)hipFree(c->nan);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -354,17 +361,25 @@ int tr_clear(tr_context* c) {
     TR_HIP(c, hipSetDevice(c->device));
     ProfScope ps(c, ST_CLEAR);
     size_t npix = (size_t)c->W * c->H;
-    // counters, covered-pixel counters and status flags in one memset
-    TR_HIP(c, hipMemsetAsync(c->state_blk, 0, (2 * kCounterSlots * 8 + 8) * sizeof(unsigned long long), c->stream));
+    {   // counters, covered-pixel counters, status flags, NaN table, scanline prefix: one launch
+        const uint32_t n_words = 2 * kCounterSlots * 8 + 8;
+        hipLaunchKernelGGL(k_clear_state, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, c->state_blk, n_words,
+                           c->nan, c->half_off);
+        TR_HIP(c, hipGetLastError());
+    }
     if (c->mode == 1) {
         // tile raster: no plane is cleared; every non-empty tile is rewritten, empty ones are never read
         TR_HIP(c, hipMemsetAsync(c->tile_cnt, 0, (size_t)c->n_tiles_padded * sizeof(uint32_t), c->stream));
-    } else {
-        // depth = "no sample yet", winner = none: both all-ones.
+    } else if (!c->planes_clean) {
+        // depth = "no sample yet", winner = none: both all-ones.  Skipped when the last resolve
+        // already left the planes cleared (the shade pass wipes what it consumes).
         TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * npix * sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(k_reset_frame, dim3(1), dim3(64), 0, c->stream, c->flags, c->nan, c->half_off);
-        TR_HIP(c, hipGetLastError());
+        c->planes_clean = true;
     }
+    c->wkey_dirty = false;
+    c->depth_upto = 0;
+    c->keys_valid = false;
+    c->cov_dirty = false;
     c->tri_total = 0;
     c->draw_count = 0;
     c->resolved = false;
@@ -531,9 +546,9 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
             // prefix of scanline counts, continuing from the previous draw's total
             const uint32_t lo = 2u * tri_base;
             uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
-            if (tiles == 1) {
-                hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
-                                   c->half_off + lo, (const unsigned long long*)nullptr, c->flags);
+            if (tiles <= 8) {
+                hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
+                                   c->half_off + lo, c->flags);
             } else {
                 hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo,
                                    n_halves, c->tile_sum);
@@ -545,10 +560,15 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
             TR_HIP(c, hipGetLastError());
         }
     }
-    if (c->mode == 0) {
+    c->keys_valid = false;
+    if (c->mode == 0 && c->depth_upto == tri_base) {
+        // depth plane is current up to this draw: add this draw's samples now.  (If an earlier
+        // resolve wiped the planes, the depth pass of the whole frame is redone at tr_resolve.)
         ProfScope ps(c, ST_DEPTH);
         rc = launch_raster(c, 0, 2u * tri_base, 2u * tri_base + n_halves);
         if (rc != TR_OK) return rc;
+        c->depth_upto = tri_base + (uint32_t)mesh->n_tris;
+        c->planes_clean = false;
     }
     c->tri_total += (uint32_t)mesh->n_tris;
     c->draw_count++;
@@ -563,10 +583,25 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
     if ((out_mask & TR_OUT_Z) && !c->z_out) TR_HIP(c, hipMalloc(&c->z_out, npix * sizeof(double)));
     if ((out_mask & TR_OUT_TRI_ID) && !c->tri_out) TR_HIP(c, hipMalloc(&c->tri_out, npix * sizeof(uint32_t)));
     if ((out_mask & TR_OUT_RGBA_F64) && !c->rgba_f64) TR_HIP(c, hipMalloc(&c->rgba_f64, npix * 4 * sizeof(double)));
-    if (!c->resolved && c->tri_total && c->mode == 0) {
-        ProfScope ps(c, ST_WINNER);
-        int rc = launch_raster(c, 1, 0u, 2u * c->tri_total);
-        if (rc != TR_OK) return rc;
+    if ((out_mask & TR_OUT_KEY) && !c->key_out) TR_HIP(c, hipMalloc(&c->key_out, npix * sizeof(unsigned long long)));
+    if (c->tri_total && c->mode == 0) {
+        if (c->depth_upto != c->tri_total) {  // planes were wiped by an earlier resolve: redo the depth pass
+            ProfScope ps(c, ST_DEPTH);
+            int rc = launch_raster(c, 0, 0u, 2u * c->tri_total);
+            if (rc != TR_OK) return rc;
+            c->depth_upto = c->tri_total;
+            c->planes_clean = false;
+            c->keys_valid = false;
+        }
+        if (!c->keys_valid) {
+            ProfScope ps(c, ST_WINNER);
+            if (c->wkey_dirty)  // draws were added after a resolve that kept its keys: start the winners over
+                TR_HIP(c, hipMemsetAsync(c->wkey, 0xFF, npix * sizeof(unsigned long long), c->stream));
+            int rc = launch_raster(c, 1, 0u, 2u * c->tri_total);
+            if (rc != TR_OK) return rc;
+            c->keys_valid = true;
+            c->wkey_dirty = true;
+        }
     }
     if (!c->resolved && c->mode == 1) {
         const uint32_t n_tiles = (uint32_t)(c->tiles_x * c->tiles_y);
@@ -609,16 +644,27 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
     {
         ProfScope ps(c, ST_SHADE);
         ShadeArgs sa;
-        sa.wkey = c->wkey; sa.rast = c->rast; sa.shade = c->shade; sa.draws = c->draw_table;
+        sa.wkey = c->wkey; sa.depth = c->depth; sa.key_out = c->key_out;
+        // the cheap path (RGBA8 only) leaves the planes cleared so the next tr_clear is free
+        sa.self_clean = (c->mode == 0 && out_mask == TR_OUT_RGBA8) ? 1 : 0;
+        sa.rast = c->rast; sa.shade = c->shade; sa.draws = c->draw_table;
         sa.nan = c->mode == 0 ? c->nan : nullptr;
         sa.tile_off = c->mode == 1 ? c->tile_off : nullptr;
         sa.tiles_x = c->tiles_x;
         sa.W = c->W; sa.H = c->H; sa.out_mask = out_mask; sa.rgba8 = c->rgba8; sa.z_out = c->z_out;
         sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.cov_counters = c->cov_counters;
-        TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
+        if (c->cov_dirty)  // a second resolve of the same frame: tr_clear zeroes them otherwise
+            TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
+        c->cov_dirty = true;
         hipLaunchKernelGGL(k_shade, dim3((c->W + kShadeBW - 1) / kShadeBW, (c->H + kShadeBH - 1) / kShadeBH), dim3(256),
                            0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
+    }
+    if (c->mode == 0 && out_mask == TR_OUT_RGBA8) {
+        c->planes_clean = true;
+        c->depth_upto = 0;
+        c->keys_valid = false;
+        c->wkey_dirty = false;
     }
     c->resolved = true;
     c->resolved_mask = out_mask;
@@ -641,31 +687,9 @@ int tr_read_triangle_id_u32(tr_context* c, uint32_t* out, int layout) {
 
 int tr_read_winner_key_u64(tr_context* c, uint64_t* out, int layout) {
     if (!c || !out) return TR_ERR_INVALID;
-    int rc = need_plane(c, TR_OUT_RGBA8);
+    int rc = need_plane(c, TR_OUT_KEY);
     if (rc != TR_OK) return rc;
-    rc = read_plane<uint64_t>(c, (const uint64_t*)c->wkey, out, layout, 1);
-    if (rc != TR_OK) return rc;
-    if (c->mode == 1) {  // tiles with an empty list hold no keys in the plane
-        size_t n_tiles = (size_t)c->tiles_x * c->tiles_y;
-        std::vector<uint32_t> off(n_tiles + 1);
-        TR_HIP(c, hipMemcpy(off.data(), c->tile_off, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (int y = 0; y < c->H; ++y)
-            for (int x = 0; x < c->W; ++x) {
-                size_t t = (size_t)(y / kTile) * c->tiles_x + (x / kTile);
-                if (off[t + 1] <= off[t] || !c->tri_total)
-                    out[layout == TR_LAYOUT_ROW_MAJOR ? (size_t)y * c->W + x : (size_t)x * c->H + y] = kKeyNone;
-            }
-        return TR_OK;
-    }
-    NanTable nt;
-    TR_HIP(c, hipMemcpy(&nt, c->nan, sizeof(nt), hipMemcpyDeviceToHost));
-    for (uint32_t s = 0; s < kNanSlots; ++s)
-        if (nt.pix[s] != kNanEmpty && nt.first_nan[s] < nt.first_any[s]) {
-            size_t x = nt.pix[s] % (uint32_t)c->W, y = nt.pix[s] / (uint32_t)c->W;
-            size_t at = layout == TR_LAYOUT_ROW_MAJOR ? y * c->W + x : x * c->H + y;
-            out[at] = nt.first_nan[s];
-        }
-    return TR_OK;
+    return read_plane<uint64_t>(c, (const uint64_t*)c->key_out, out, layout, 1);
 }
 
 int tr_read_rgba8(tr_context* c, uint8_t* out, int flip) {

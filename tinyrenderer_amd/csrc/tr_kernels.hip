@@ -388,6 +388,39 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __r
     }
 }
 
+// single block: the whole scan for up to a few tiles (one launch instead of three)
+__global__ __launch_bounds__(kScanThreads) void k_scan_small(const uint32_t* __restrict__ cnt, uint32_t n,
+                                                             uint32_t* off, uint32_t* flags) {
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = off[0];
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n; t0 += kScanTile) {
+        uint32_t begin = t0 + threadIdx.x * kScanPer;
+        uint32_t v[kScanPer];
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < kScanPer; ++i) {
+            v[i] = (begin + i < n) ? cnt[begin + i] : 0u;
+            s += v[i];
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(s, &tot);
+        unsigned long long base = carry;
+        uint32_t run = (uint32_t)base + ex;
+#pragma unroll
+        for (int i = 0; i < kScanPer; ++i) {
+            run += v[i];
+            if (begin + i < n) off[begin + i + 1] = run;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            carry = base + tot;
+            if (base + tot > 0xFFFFFFFFull) atomicOr(flags, 1u << 4);
+        }
+        __syncthreads();
+    }
+}
+
 // =============================================================== (3) raster
 // One workgroup per chunk of 64 consecutive scanlines of the frame-global scanline sequence.
 // Lanes of wave 0 first own one scanline each (find its half by binary search in half_off, build A and
@@ -541,7 +574,10 @@ template __global__ void k_raster<1, false>(RasterArgs);
 
 // ================================================================ (4) shade
 struct ShadeArgs {
-    const unsigned long long* wkey;
+    unsigned long long* wkey;
+    unsigned long long* depth;   // global raster: cleaned together with wkey when self_clean
+    int self_clean;              // write "none" back over every depth / key this pass consumes
+    unsigned long long* key_out; // optional copy of the winner keys (TR_OUT_KEY)
     const TriRaster* rast;
     const TriShade* shade;
     const DrawDev* draws;
@@ -613,6 +649,10 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         listed = a.tile_off[tile + 1] > a.tile_off[tile];
     }
     unsigned long long key = listed ? a.wkey[pix] : kKeyNone;
+    if (a.self_clean && key != kKeyNone) {  // leave the planes cleared for the next frame
+        a.wkey[pix] = kKeyNone;
+        a.depth[pix] = kKeyNone;
+    }
     if (a.nan && live && a.nan->pix[0] != kNanEmpty) {
         for (uint32_t s = 0; s < kNanSlots; ++s)
             if (a.nan->pix[s] == pix && a.nan->first_nan[s] < a.nan->first_any[s]) key = a.nan->first_nan[s];
@@ -684,6 +724,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     }
     a.rgba8[pix] = f64_as_u8(col[0]) | (f64_as_u8(col[1]) << 8) | (f64_as_u8(col[2]) << 16) |
                    (f64_as_u8(col[3]) << 24);
+    if (a.out_mask & 16u) a.key_out[pix] = key;
     if (a.out_mask & 2u) a.z_out[pix] = zval;
     if (a.out_mask & 4u) a.tri_out[pix] = tri;
     if (a.out_mask & 8u) {
@@ -700,13 +741,20 @@ __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* p, size_t 
     for (; i < n; i += stride) p[i] = v;
 }
 
-__global__ void k_reset_frame(uint32_t* flags, NanTable* nan, uint32_t* half_off) {
-    int t = threadIdx.x;
-    if (t == 0) { *flags = 0; half_off[0] = 0; }
-    if (t < (int)kNanSlots) {
-        nan->pix[t] = kNanEmpty;
-        nan->first_nan[t] = kKeyNone;
-        nan->first_any[t] = kKeyNone;
+// One launch per tr_clear: zero the counter slots and status flags, empty the NaN side table,
+// restart the scanline prefix.
+__global__ __launch_bounds__(256) void k_clear_state(unsigned long long* state_blk, uint32_t n_words, NanTable* nan,
+                                                     uint32_t* half_off) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) state_blk[i] = 0ull;
+    if (blockIdx.x == 0) {
+        int t = threadIdx.x;
+        if (t == 0) half_off[0] = 0;
+        if (t < (int)kNanSlots) {
+            nan->pix[t] = kNanEmpty;
+            nan->first_nan[t] = kKeyNone;
+            nan->first_any[t] = kKeyNone;
+        }
     }
 }
 
