@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=30)
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("TR_BENCH_CONTEXTS", "2")),
+                    help="render contexts (HIP streams) used round-robin: frames of successive steps overlap")
     args = ap.parse_args()
 
     import torch
@@ -81,9 +83,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal on a one-GPU box only: TR_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # TR_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    if os.environ.get("TR_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("TR_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from tinyrenderer_amd import _ffi
     from tinyrenderer_amd.model_renderer import ModelRendererState, make_draw_params
@@ -91,22 +101,29 @@ def main():
     lib = _ffi.load()
     W, H = args.width, args.height
     draws = build_scene(W, H)
-    st = ModelRendererState(W, H, device=local_rank)
+    states = [ModelRendererState(W, H, device=local_rank) for _ in range(max(1, args.contexts))]
+    st = states[0]
     ctx = st._ctx
-    prepared = [(st._mesh_handle(mc.mesh), make_draw_params(st, sh, mc.texture, mc.normal_map)) for mc, sh in draws]
+    prepared_all = [[(s._mesh_handle(mc.mesh), make_draw_params(s, sh, mc.texture, mc.normal_map)) for mc, sh in draws]
+                    for s in states]
+    turn = [0]
 
-    def frame():
-        lib.tr_clear(ctx)
-        for mesh_h, params in prepared:
-            rc = lib.tr_draw(ctx, mesh_h, C.byref(params))
+    def frame(which=None):
+        k = turn[0] % len(states) if which is None else which
+        turn[0] += 1
+        cx = states[k]._ctx
+        lib.tr_clear(cx)
+        for mesh_h, params in prepared_all[k]:
+            rc = lib.tr_draw(cx, mesh_h, C.byref(params))
             if rc != 0:
-                _ffi.check(ctx, rc, "tr_draw")
-        rc = lib.tr_resolve(ctx, _ffi.TR_OUT_RGBA8)
+                _ffi.check(cx, rc, "tr_draw")
+        rc = lib.tr_resolve(cx, _ffi.TR_OUT_RGBA8)
         if rc != 0:
-            _ffi.check(ctx, rc, "tr_resolve")
+            _ffi.check(cx, rc, "tr_resolve")
 
     def sync():
-        lib.tr_synchronize(ctx)
+        for s in states:
+            lib.tr_synchronize(s._ctx)
         torch.cuda.synchronize()
 
     def barrier():
@@ -129,7 +146,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -145,7 +162,7 @@ def main():
     cnt = (C.c_uint64 * 6)()
     lib.tr_profile_read(ctx, ms, cnt, 1)
     for _ in range(args.profile_frames):
-        frame()
+        frame(0)
     sync()
     lib.tr_profile_read(ctx, ms, cnt, 1)
     lib.tr_profile_enable(ctx, 0)
@@ -164,6 +181,13 @@ def main():
                 seen.add(id(img))
                 tex_bytes += min(img.shape[0] * img.shape[1] * 4, shaded_px * 16)
     shade_bytes = W * H * 12 + vis_tris * 320 + tex_bytes
+    traffic = None
+    try:  # HBM bytes per k_shade launch from the committed PMC passes (same workload only)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_pmc_4k.json")))
+        if pmc["workload"]["W"] == W and pmc["workload"]["H"] == H:
+            traffic = pmc["k_shade_hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     shade_s = stages_us["shade"] * 1e-6
     achieved = shade_bytes / shade_s / 1e9 if shade_s > 0 else 0.0
 
@@ -173,17 +197,18 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "reference assets (african_head.obj + diffuse/nm_tangent PNG), fixed frame time=1",
         "config": {"workload": f"african_head {W}x{H} single frame, 1 draw (BASELINE.json configs[2])",
-                   "frames_per_rank_per_step": 1, "parallelism": f"views x{world}" if world > 1 else "single GPU"},
+                   "frames_per_rank_per_step": 1, "contexts_per_gpu": len(states), "parallelism": f"views x{world}" if world > 1 else "single GPU"},
         "mfragments_per_s": fps * frags / 1e6,
         "fragments_per_frame": frags, "samples_per_frame": counters["samples"], "shaded_px_per_frame": shaded_px,
         "stages_us": stages_us,
         "roofline": {"bound": "hbm", "kernel": "k_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes": shade_bytes, "avg_launch_us": stages_us["shade"]},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, draws)
-    st.close()
+    for s_ in states:
+        s_.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -304,3 +304,28 @@ def test_frame_reuse_and_late_plane_requests(oracle, mode):
         assert np.isneginf(st.z_buffer).all()
     finally:
         st.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_config4_subdivided_mesh_bands(oracle, mode):
+    """BASELINE.json configs[3] at reduced scale: african_head subdivided 3x (159 488 triangles
+    of a few pixels), rendered whole and as 2 tile-row bands that must stack to the same frame."""
+    from tinyrenderer_amd import sharding
+    from tinyrenderer_amd.model_renderer import MeshComponent
+
+    W, Hh = 960, 544
+    head = SU.component("head")
+    fine = MeshComponent(scenes.subdivide(head.mesh, 3), head.texture, head.normal_map)
+    assert fine.mesh.triangles.shape[0] == 2492 * 64
+    fine.transform.set_rotation((0.025, 0.0, 0.0))
+    draws = [(fine, scenes.shader_for(fine, W, Hh))]
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    g = SU.gpu_render(W, Hh, draws, mode=mode)
+    info = SU.assert_parity(o, g)
+    assert info["f64_colour_mismatches"] == 0
+    key = np.full_like(g["key"], np.uint64(0xFFFFFFFFFFFFFFFF))
+    for r in range(2):
+        y_lo, y_hi = sharding.band_rows(Hh, r, 2)
+        b = SU.gpu_render(W, Hh, draws, mode=mode, band=(y_lo, y_hi))
+        key[:, y_lo:y_hi] = b["key"][:, y_lo:y_hi]
+    assert np.array_equal(key, g["key"])

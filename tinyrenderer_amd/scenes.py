@@ -45,3 +45,42 @@ def shader_for(mesh_component, frame_width, frame_height, eye=(0.0, 0.0, 2.0), u
     cam_pos, view = camera(eye)
     mv = H.mat4_mul(view, mesh_component.local_to_world_matrix())
     return BuiltinShader(perspective(frame_width, frame_height), mv, cam_pos, use_normal_map=use_normal_map)
+
+
+def subdivide(obj, levels):
+    """split every triangle by its edge midpoints `levels` times
+    (4**levels times the triangles); positions, normals and uvw of a midpoint are (a + b) * 0.5.
+    Midpoints are not shared between neighbouring triangles (the renderer never shares vertices)."""
+    import numpy as np
+
+    v, t, n, tri = obj.vertices, obj.tex_vertices, obj.normals, obj.triangles.astype(np.int64)
+    for _ in range(levels):
+        T = tri.shape[0]
+        out = np.empty((4 * T, 9), dtype=np.int64)
+        new_attrs = []
+        for k, arr in enumerate((v, t, n)):  # index column k of each corner: v, vt, vn
+            idx = tri[:, [k, 3 + k, 6 + k]]  # (T, 3) corner indices a, b, c
+            none = idx[:, 0] == H.NONE_INDEX
+            if arr.shape[0] == 0 or none.all():
+                new_attrs.append(arr)
+                for c in range(4):
+                    out[c::4, [k, 3 + k, 6 + k]] = H.NONE_INDEX
+                continue
+            safe = np.where(idx == H.NONE_INDEX, 0, idx)
+            a, b, c_ = arr[safe[:, 0]], arr[safe[:, 1]], arr[safe[:, 2]]
+            mab, mbc, mca = (a + b) * 0.5, (b + c_) * 0.5, (c_ + a) * 0.5
+            base = arr.shape[0]
+            arr2 = np.concatenate([arr, mab, mbc, mca], axis=0)
+            iab = base + np.arange(T)
+            ibc = base + T + np.arange(T)
+            ica = base + 2 * T + np.arange(T)
+            ia, ib, ic = idx[:, 0], idx[:, 1], idx[:, 2]
+            corners = [(ia, iab, ica), (iab, ib, ibc), (ica, ibc, ic), (iab, ibc, ica)]
+            for c, (p, q, r) in enumerate(corners):
+                out[c::4, k] = np.where(none, H.NONE_INDEX, p)
+                out[c::4, 3 + k] = np.where(none, H.NONE_INDEX, q)
+                out[c::4, 6 + k] = np.where(none, H.NONE_INDEX, r)
+            new_attrs.append(arr2)
+        v, t, n = new_attrs
+        tri = out
+    return H.Object(v, t, n, tri.astype(np.uint32), obj.name)
