@@ -168,6 +168,32 @@ int tr_device_ptr_rgba8(tr_context* ctx, void** out_dev_ptr); /* u32[W*H], row-m
 int tr_profile_enable(tr_context* ctx, int enable);
 int tr_profile_read(tr_context* ctx, double ms[6], uint64_t counts[6], int reset);
 
+/* ---- loading surface (host only; no context or GPU needed) ------------------------------
+ * Replace helpers::load_model (src/helpers/mod.rs:352-355: wavefront_obj::obj::parse, first
+ * object; only the triangles of geometry[0] are kept because that is all the renderer draws,
+ * src/model_renderer/mod.rs:237; polygons are fan-triangulated, indices are 0-based, 0xFFFFFFFF
+ * = None) and helpers::load_rgba_img_from_file (+ flip_vertically) (src/helpers/mod.rs:93-96,
+ * 291-302: image::open(..).into_rgba8()).  PNG: 8-bit grey / grey+alpha / RGB / RGBA / palette,
+ * non-interlaced.  TGA: types 2, 3, 10, 11.  The arrays returned by the accessors have the
+ * layout tr_mesh_create / tr_texture_create take and live until the object is freed.
+ * tr_load_error() gives text for the calling thread's last loader failure. */
+typedef struct tr_obj tr_obj;
+typedef struct tr_image tr_image;
+int tr_obj_load(const char* path, tr_obj** out);
+int tr_obj_parse(const char* text, int64_t len, tr_obj** out);
+int tr_obj_counts(const tr_obj* obj, int64_t* n_positions, int64_t* n_uvw, int64_t* n_normals,
+                  int64_t* n_triangles);
+const double* tr_obj_positions(const tr_obj* obj);
+const double* tr_obj_uvw(const tr_obj* obj);
+const double* tr_obj_normals(const tr_obj* obj);
+const uint32_t* tr_obj_indices(const tr_obj* obj);
+void tr_obj_free(tr_obj* obj);
+int tr_image_load_rgba8(const char* path, int flip_vertically, tr_image** out);
+int tr_image_size(const tr_image* img, int* width, int* height);
+const uint8_t* tr_image_data(const tr_image* img);
+void tr_image_free(tr_image* img);
+const char* tr_load_error(void);
+
 /* Library identity: returns a static string with the build's target arch and ABI version. */
 const char* tr_version(void);
 

@@ -1,0 +1,191 @@
+"""Native loading surface (tr_obj_*, tr_image_*; include/tinyrenderer_hip.h) against independent
+decoders: the pure-Python OBJ restatement in helpers.parse_obj and PIL for PNG / TGA.  CPU only.
+Mirrors the reference's load path: helpers::load_model (src/helpers/mod.rs:352-355) and
+load_rgba_img_from_file + flip_vertically (src/helpers/mod.rs:93-96, 291-302)."""
+import glob
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tinyrenderer_amd import _ffi
+from tinyrenderer_amd import helpers as H
+
+PIL = pytest.importorskip("PIL.Image")
+
+OBJS = sorted(glob.glob(os.path.join(H.ASSET_DIR, "*", "*.obj")))
+PNGS = sorted(glob.glob(os.path.join(H.ASSET_DIR, "*", "*.png")))
+
+
+def same_object(a, b):
+    for k in ("vertices", "tex_vertices", "normals", "triangles"):
+        x, y = getattr(a, k), getattr(b, k)
+        assert x.shape == y.shape, k
+        assert np.array_equal(x, y), k
+
+
+@pytest.mark.parametrize("path", OBJS, ids=[os.path.basename(p) for p in OBJS])
+def test_obj_assets_match_python_parser(path):
+    assert OBJS
+    same_object(H.load_model(path), H.parse_obj(open(path).read()))
+
+
+OBJ_VARIANTS = {
+    "quad_fan_negative_indices": "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 0 1\nf -4/-4/-1 -3/-3/-1 -2/-2/-1 -1/-1/-1\n",
+    "no_uv_no_normals": "# c\nv 0.5 -1e-3 2\nv 1 0 0\nv 0 1 0\nf 1 2 3\n",
+    "v_slash_slash_n": "v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n",
+    "crlf_and_tabs": "o thing\r\nv\t0 0 0\r\nv 1 0 0\r\nv 0 1 0\r\nvt 0.25 0.75 0\r\nf 1/1 2/1 3/1\r\n",
+    "second_object_ignored": "o a\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\no b\nv 5 5 5\nf 1 2 4\n",
+    "second_material_ignored": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 1\nusemtl m0\nf 1 2 3\nusemtl m1\nf 2 3 4\n",
+    "groups_and_smoothing": "g grp\ns 1\nv 0 0 0\nv 1 0 0\nv 0 1 0\ns off\nf 1 2 3\n",
+    "empty": "",
+}
+
+
+@pytest.mark.parametrize("name", sorted(OBJ_VARIANTS))
+def test_obj_variants_match_python_parser(name):
+    text = OBJ_VARIANTS[name]
+    same_object(H.parse_obj_native(text), H.parse_obj(text))
+
+
+def test_obj_errors_are_reported():
+    with pytest.raises(_ffi.TrError):
+        H.parse_obj_native("v 0 0 0\nf 1 2 3\n")  # index out of range
+    with pytest.raises(_ffi.TrError):
+        H.parse_obj_native("v 0 zero 0\n")
+    with pytest.raises(_ffi.TrError):
+        H.load_model("/nonexistent/none.obj")
+
+
+@pytest.mark.parametrize("path", PNGS, ids=[os.path.basename(p) for p in PNGS])
+def test_png_assets_match_pil(path):
+    want = np.asarray(PIL.open(path).convert("RGBA"))
+    got = H.load_rgba_img_from_file(path)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(H.load_rgba_img_from_file(path, flip=True), want[::-1])
+    assert np.array_equal(H.flip_vertically(got), want[::-1])
+
+
+def _rand_img(mode, w, h, seed):
+    rng = np.random.default_rng(seed)
+    ch = {"L": 1, "LA": 2, "RGB": 3, "RGBA": 4}[mode]
+    a = rng.integers(0, 256, size=(h, w, ch), dtype=np.uint8)
+    return PIL.fromarray(a[..., 0] if ch == 1 else a, mode)
+
+
+@pytest.mark.parametrize("mode", ["L", "LA", "RGB", "RGBA"])
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (64, 33)])
+def test_png_colour_types_match_pil(tmp_path, mode, size):
+    im = _rand_img(mode, size[0], size[1], seed=hash((mode, size)) & 0xFFFF)
+    for k, kw in enumerate([{}, {"compress_level": 0}, {"optimize": True}]):
+        p = str(tmp_path / f"{mode}_{k}.png")
+        im.save(p, **kw)
+        assert np.array_equal(H.load_rgba_img_from_file(p), np.asarray(im.convert("RGBA")))
+
+
+def test_png_palette_with_and_without_trns(tmp_path):
+    rgb = _rand_img("RGB", 40, 30, 7).quantize(colors=17)
+    p = str(tmp_path / "pal.png")
+    rgb.save(p)
+    assert np.array_equal(H.load_rgba_img_from_file(p), np.asarray(rgb.convert("RGBA")))
+    p2 = str(tmp_path / "pal_t.png")
+    rgb.save(p2, transparency=bytes([0, 128, 255] + [255] * 14))
+    assert np.array_equal(H.load_rgba_img_from_file(p2), np.asarray(PIL.open(p2).convert("RGBA")))
+
+
+def test_png_all_filter_types(tmp_path):
+    """Hand-built PNG whose scanlines use filter types 0..4 in turn."""
+    import zlib
+
+    w, h, bpp = 9, 10, 4
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 256, size=(h, w * bpp), dtype=np.uint8).astype(np.int32)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    stream = bytearray()
+    for y in range(h):
+        ft = y % 5
+        stream.append(ft)
+        for x in range(w * bpp):
+            a = raw[y, x - bpp] if x >= bpp else 0
+            b = raw[y - 1, x] if y else 0
+            c = raw[y - 1, x - bpp] if (y and x >= bpp) else 0
+            pred = [0, a, b, (a + b) // 2, paeth(int(a), int(b), int(c))][ft]
+            stream.append((int(raw[y, x]) - int(pred)) & 0xFF)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    z = zlib.compress(bytes(stream))
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0))
+           + chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b""))
+    p = str(tmp_path / "filters.png")
+    open(p, "wb").write(png)
+    want = raw.astype(np.uint8).reshape(h, w, 4)
+    assert np.array_equal(np.asarray(PIL.open(p).convert("RGBA")), want)  # the file itself is valid
+    assert np.array_equal(H.load_rgba_img_from_file(p), want)
+
+
+def _tga(w, h, bpp, pixels_bgra, rle=False, top_left=False, grey=False):
+    itype = (3 if grey else 2) + (8 if rle else 0)
+    desc = (0x20 if top_left else 0) | (8 if bpp == 32 else 0)
+    hdr = struct.pack("<BBBHHBHHHHBB", 0, 0, itype, 0, 0, 0, 0, 0, w, h, bpp, desc)
+    px = [bytes(p) for p in pixels_bgra]
+    if not rle:
+        return hdr + b"".join(px)
+    out = bytearray()
+    for y in range(h):  # TGA 2.0: packets do not cross scanlines
+        row = px[y * w:(y + 1) * w]
+        i = 0
+        while i < len(row):
+            run = 1
+            while i + run < len(row) and run < 128 and row[i + run] == row[i]:
+                run += 1
+            if run > 1:
+                out.append(0x80 | (run - 1))
+                out += row[i]
+                i += run
+            else:
+                lit = 1
+                while i + lit < len(row) and lit < 128 and row[i + lit] != row[i + lit - 1]:
+                    lit += 1
+                out.append(lit - 1)
+                out += b"".join(row[i:i + lit])
+                i += lit
+    return hdr + bytes(out)
+
+
+@pytest.mark.parametrize("bpp,grey", [(24, False), (32, False), (8, True)])
+@pytest.mark.parametrize("rle", [False, True])
+@pytest.mark.parametrize("top_left", [False, True])
+def test_tga_matches_pil(tmp_path, bpp, grey, rle, top_left):
+    w, h = 13, 9
+    rng = np.random.default_rng(bpp + rle * 2 + top_left)
+    nb = bpp // 8
+    a = rng.integers(0, 4, size=(h * w, nb), dtype=np.uint8) * 60  # few levels -> real RLE runs
+    a[5:40] = a[5]
+    data = _tga(w, h, bpp, a, rle=rle, top_left=top_left, grey=grey)
+    p = str(tmp_path / "t.tga")
+    open(p, "wb").write(data)
+    want = np.asarray(PIL.open(p).convert("RGBA"))
+    got = H.load_rgba_img_from_file(p)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(H.load_rgba_img_from_file(p, flip=True), want[::-1])
+
+
+def test_image_errors_are_reported(tmp_path):
+    p = str(tmp_path / "bad.png")
+    open(p, "wb").write(b"\x89PNG\r\n\x1a\n" + b"\0" * 20)
+    with pytest.raises(_ffi.TrError):
+        H.load_rgba_img_from_file(p)
+    with pytest.raises(_ffi.TrError):
+        H.load_rgba_img_from_file(str(tmp_path / "missing.png"))
+    q = str(tmp_path / "trunc.tga")
+    open(q, "wb").write(_tga(4, 4, 24, np.zeros((16, 3), np.uint8))[:30])
+    with pytest.raises(_ffi.TrError):
+        H.load_rgba_img_from_file(q)

@@ -37,7 +37,9 @@ EXPORTS = [
     "tr_read_triangle_id_u32", "tr_read_winner_key_u64", "tr_read_rgba8", "tr_read_rgba_f64",
     "tr_get_counters", "tr_get_status_flags", "tr_synchronize", "tr_get_stream",
     "tr_device_ptr_rgba8", "tr_profile_enable", "tr_profile_read", "tr_version", "tr_set_band",
-    "tr_set_raster_mode",
+    "tr_set_raster_mode", "tr_obj_load", "tr_obj_parse", "tr_obj_counts", "tr_obj_positions", "tr_obj_uvw",
+    "tr_obj_normals", "tr_obj_indices", "tr_obj_free", "tr_image_load_rgba8", "tr_image_size", "tr_image_data",
+    "tr_image_free", "tr_load_error",
 ]
 
 
@@ -98,6 +100,19 @@ def load():
         "tr_version": (C.c_char_p, []),
         "tr_set_band": (i32, [vp, i32, i32]),
         "tr_set_raster_mode": (i32, [vp, i32]),
+        "tr_obj_load": (i32, [C.c_char_p, C.POINTER(vp)]),
+        "tr_obj_parse": (i32, [C.c_char_p, i64, C.POINTER(vp)]),
+        "tr_obj_counts": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+        "tr_obj_positions": (pd, [vp]),
+        "tr_obj_uvw": (pd, [vp]),
+        "tr_obj_normals": (pd, [vp]),
+        "tr_obj_indices": (C.POINTER(C.c_uint32), [vp]),
+        "tr_obj_free": (None, [vp]),
+        "tr_image_load_rgba8": (i32, [C.c_char_p, i32, C.POINTER(vp)]),
+        "tr_image_size": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+        "tr_image_data": (C.POINTER(C.c_uint8), [vp]),
+        "tr_image_free": (None, [vp]),
+        "tr_load_error": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -225,23 +225,78 @@ def parse_obj(text):
     )
 
 
+def _native():
+    from . import _ffi
+
+    return _ffi, _ffi.load()
+
+
+def _object_from_native(lib, h):
+    import ctypes as C
+
+    n = [C.c_int64() for _ in range(4)]
+    lib.tr_obj_counts(h, *[C.byref(x) for x in n])
+    n_pos, n_uvw, n_nrm, n_tri = (int(x.value) for x in n)
+
+    def arr(ptr, count, dtype):
+        if count == 0:
+            return np.zeros((0,), dtype=dtype)
+        return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True)
+
+    return Object(arr(lib.tr_obj_positions(h), 3 * n_pos, np.float64), arr(lib.tr_obj_uvw(h), 3 * n_uvw, np.float64),
+                  arr(lib.tr_obj_normals(h), 3 * n_nrm, np.float64), arr(lib.tr_obj_indices(h), 9 * n_tri, np.uint32))
+
+
 def load_model(path):
-    """src/helpers/mod.rs:352-355."""
-    with open(path, "r") as fh:
-        return parse_obj(fh.read())
+    """src/helpers/mod.rs:352-355, through the library's native OBJ parser (`tr_obj_load`)."""
+    import ctypes as C
+
+    ffi, lib = _native()
+    h = C.c_void_p()
+    rc = lib.tr_obj_load(os.fsencode(path), C.byref(h))
+    if rc != ffi.TR_OK:
+        raise ffi.TrError(f"tr_obj_load({path}): {ffi.TR_ERR.get(rc, rc)} {lib.tr_load_error().decode(errors='replace')}")
+    try:
+        return _object_from_native(lib, h)
+    finally:
+        lib.tr_obj_free(h)
 
 
-def load_rgba_img_from_file(path):
-    """src/helpers/mod.rs:93-96: `image::open(path)?.into_rgba8()` -> (H, W, 4) uint8, row 0 = top.
+def parse_obj_native(text):
+    """`wavefront_obj::obj::parse` on a string through the library (`tr_obj_parse`)."""
+    import ctypes as C
 
-    8-bit L / LA / RGB / RGBA PNGs expand exactly as `into_rgba8` does (L -> l,l,l,255;
-    LA -> l,l,l,a; RGB -> a = 255); no gamma or colour management is applied."""
-    from PIL import Image  # plumbing: lossless PNG decode
+    ffi, lib = _native()
+    data = text.encode()
+    h = C.c_void_p()
+    rc = lib.tr_obj_parse(data, len(data), C.byref(h))
+    if rc != ffi.TR_OK:
+        raise ffi.TrError(f"tr_obj_parse: {ffi.TR_ERR.get(rc, rc)} {lib.tr_load_error().decode(errors='replace')}")
+    try:
+        return _object_from_native(lib, h)
+    finally:
+        lib.tr_obj_free(h)
 
-    with Image.open(path) as im:
-        if im.mode not in ("L", "LA", "RGB", "RGBA"):
-            raise ValueError(f"unsupported image mode {im.mode} in {path}")
-        return np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))
+
+def load_rgba_img_from_file(path, flip=False):
+    """src/helpers/mod.rs:93-96: `image::open(path)?.into_rgba8()` -> (H, W, 4) uint8, row 0 = top
+    (row 0 = bottom with flip=True, i.e. followed by `flip_vertically`).  Decoded by the library's
+    own PNG / TGA reader (`tr_image_load_rgba8`): 8-bit L / LA / RGB / RGBA expand exactly as
+    `into_rgba8` does (L -> l,l,l,255; LA -> l,l,l,a; RGB -> a = 255); no gamma is applied."""
+    import ctypes as C
+
+    ffi, lib = _native()
+    h = C.c_void_p()
+    rc = lib.tr_image_load_rgba8(os.fsencode(path), 1 if flip else 0, C.byref(h))
+    if rc != ffi.TR_OK:
+        raise ffi.TrError(f"tr_image_load_rgba8({path}): {ffi.TR_ERR.get(rc, rc)} {lib.tr_load_error().decode(errors='replace')}")
+    try:
+        w, hh = C.c_int(), C.c_int()
+        lib.tr_image_size(h, C.byref(w), C.byref(hh))
+        data = np.ctypeslib.as_array(lib.tr_image_data(h), shape=(hh.value * w.value * 4,))
+        return data.reshape(hh.value, w.value, 4).copy()
+    finally:
+        lib.tr_image_free(h)
 
 
 def flip_vertically(img):
