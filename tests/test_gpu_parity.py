@@ -329,3 +329,110 @@ def test_config4_subdivided_mesh_bands(oracle, mode):
         b = SU.gpu_render(W, Hh, draws, mode=mode, band=(y_lo, y_hi))
         key[:, y_lo:y_hi] = b["key"][:, y_lo:y_hi]
     assert np.array_equal(key, g["key"])
+
+
+def test_scanline_record_overflow_falls_back(oracle, monkeypatch):
+    """Global raster: slots beyond the record buffer (TR_SCAN_RECORDS) are rebuilt by every pass;
+    results and counters do not depend on the capacity."""
+    W, Hh = 400, 300
+    draws = _head_scene(W, Hh, with_eye=True)
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    for cap in ("0", "1000", "20011"):
+        monkeypatch.setenv("TR_SCAN_RECORDS", cap)
+        g = SU.gpu_render(W, Hh, draws, mode=0)
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], (cap, k)
+
+
+def test_counters_over_an_extended_frame(oracle):
+    """draw, fast resolve (wipes the planes), draw, resolve: the depth pass of the whole frame is
+    redone, but every sample is counted once."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 320, 200
+    draws = _head_scene(W, Hh, with_eye=True)
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    st = ModelRendererState(W, Hh, raster_mode=0)
+    try:
+        clear_screen(st)
+        render_mesh_component(st, *draws[0])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        render_mesh_component(st, *draws[1])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        c = st.counters()
+        for k in ("samples", "fragments", "scanlines"):
+            assert c[k] == o["counters"][k], k
+        assert np.array_equal(st.present(), o["present"])
+    finally:
+        st.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_large_and_tiny_triangles_mixed(oracle, mode):
+    """Triangles from a few pixels to most of a 4K-wide frame in one draw: exercises the slot
+    padding that balances the global raster's chunks (slot_shift 0..5)."""
+    from tinyrenderer_amd import helpers as H_
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    W, Hh = 2048, 256
+    rng = np.random.default_rng(11)
+    n_v = 60
+    v = np.zeros((n_v, 3))
+    v[:, 0] = rng.uniform(-0.98, 0.98, n_v)
+    v[:, 1] = rng.uniform(-0.98, 0.98, n_v)
+    v[:, 2] = rng.uniform(-0.9, 0.9, n_v)
+    vt = rng.uniform(0.02, 0.98, (n_v, 3))
+    vn = rng.normal(size=(n_v, 3))
+    tris = []
+    for k in range(24):  # big
+        a, b, c = rng.choice(n_v, 3, replace=False)
+        tris.append([a, a, a, b, b, b, c, c, c])
+    order = np.argsort(v[:, 0])
+    for k in range(n_v - 2):  # slivers / small
+        a, b, c = order[k], order[k + 1], order[k + 2]
+        tris.append([a, a, a, b, b, b, c, c, c])
+    obj = H_.Object(v.reshape(-1), vt.reshape(-1), vn.reshape(-1), np.array(tris, dtype=np.uint32).reshape(-1))
+    mc = _synthetic_component(obj, seed=5)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.3, 0.2, 1.0))
+    draws = [(mc, sh)]
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    g = SU.gpu_render(W, Hh, draws, mode=mode)
+    info = SU.assert_parity(o, g)
+    assert info["f64_colour_mismatches"] == 0 and info["covered"] > 10000
+    if mode == 0:
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], k
+
+
+def test_background_blocks_are_repainted_between_frames(oracle):
+    """The RGBA8-only resolve leaves blocks alone that hold no key and are already background
+    colour: frames with different coverage on one context must still come out whole."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 400, 240
+    head, eye_mc = SU.component("head"), SU.component("eye_inner")
+    eye_mc.parent = None
+    views = [[(head, scenes.shader_for(head, W, Hh, eye=(0.0, 0.0, 2.0)))],
+             [(eye_mc, scenes.shader_for(eye_mc, W, Hh, eye=(1.5, 0.3, 4.0)))],
+             [],
+             [(head, scenes.shader_for(head, W, Hh, eye=(-2.0, 0.5, 3.0)))],
+             [(eye_mc, scenes.shader_for(eye_mc, W, Hh, eye=(0.0, 0.0, 2.0)))]]
+    st = ModelRendererState(W, Hh, raster_mode=0)
+    try:
+        for k, draws in enumerate(views):
+            clear_screen(st)
+            for d in draws:
+                render_mesh_component(st, *d)
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            want = SU.oracle_render(oracle, W, Hh, draws)["present"]
+            assert np.array_equal(st.present(), want), f"view {k}"
+            if k == 3:  # a late plane request in between must not confuse the block flags
+                assert np.array_equal(st.winner_keys(), SU.oracle_render(oracle, W, Hh, draws)["key"])
+                assert np.array_equal(st.present(), want)
+    finally:
+        st.close()
+        eye_mc.parent = head

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinyrenderer_hip.so")
+# (TINYRENDERER_HIP_LIB: an alternative build of the same library, for A/B timing)
+LIB_PATH = os.environ.get("TINYRENDERER_HIP_LIB") or os.path.join(_HERE, "libtinyrenderer_hip.so")
 
 TR_OK = 0
 TR_ERR = {

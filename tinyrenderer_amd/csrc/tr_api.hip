@@ -54,6 +54,14 @@ struct tr_context {
     TriShade* shade = nullptr;
     uint32_t* half_cnt = nullptr;
     uint32_t* half_off = nullptr;
+    ScanRec* rec = nullptr;          // scanline records of the frame's first rec_cap slots
+    uint32_t rec_cap = 1u << 20;     // 64 MB; slots beyond are rebuilt by every raster pass (TR_SCAN_RECORDS)
+    uint8_t* chunk_live = nullptr;
+    uint8_t* blk_flags = nullptr;    // [0, n_blk): touched this frame, [n_blk, 2 n_blk): rgba8 not background
+    uint32_t n_blk = 0;
+    int blocks_x = 0;
+    bool skip_clean = true;          // shade pass skips blocks that hold no key and are already background
+    uint32_t counted_upto = 0;       // triangles whose samples are in the counters
     size_t tri_cap = 0;
     unsigned long long* tile_sum = nullptr;
     size_t tile_cap = 0;
@@ -84,6 +92,7 @@ struct tr_context {
     // profiling
     bool precheck = true;          // plain-load filter in front of the depth atomics
     bool precheck_winner = false;  // ... and in front of the winner atomics
+    bool skip_dead = true;         // winner pass skips chunks the depth pass found dead
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double prof_ms[ST_COUNT] = {0};
@@ -184,15 +193,18 @@ int ensure_scratch(tr_context* c, double** p, size_t* cap, size_t need) {
 }
 
 constexpr int kRasterBlocks = 4096;
+constexpr uint32_t kChunkLiveCap = 1u << 20;  // 64 M slots per frame get dead-chunk skipping
 
-int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi) {
-    RasterArgs ra;
+void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_hi) {
     ra.half_off = c->half_off;
     ra.rast = c->rast;
+    ra.rec = c->rec;
+    ra.rec_cap = c->rec_cap;
     ra.depth = c->depth;
     ra.wkey = c->wkey;
     ra.h_lo = h_lo;
     ra.h_hi = h_hi;
+    ra.count_h = 2u * c->counted_upto;
     ra.W = c->W;
     ra.H = c->H;
     ra.y_lo = c->y_lo;
@@ -200,10 +212,49 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi) {
     ra.counters = c->counters;
     ra.flags = c->flags;
     ra.nan = c->nan;
-    dim3 grid(kRasterBlocks), block(kRasterThreads);
+    ra.blk_touched = c->blk_flags;
+    ra.blocks_x = c->blocks_x;
+    ra.chunk_live = c->chunk_live;
+    ra.live_cap = kChunkLiveCap;
+    ra.use_live = 0;
+    ra.debug = 0;
+    ra.trace = nullptr;
+    ra.trace_cap = 0;
+}
+
+// passes 0 / 1 over the half range [h_lo, h_hi)
+int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool use_live = false) {
+    RasterArgs ra;
+    fill_raster_args(c, ra, h_lo, h_hi);
+    ra.use_live = use_live && c->skip_dead ? 1 : 0;
+    if (const char* e = std::getenv("TR_RASTER_DEBUG")) ra.debug = std::atoi(e);
+    static const char* trace_path = std::getenv("TR_RASTER_TRACE");  // debugging aid, see tools/raster_trace.py
+    static unsigned long long* trace_buf = nullptr;
+    constexpr uint32_t kTraceCap = 1u << 16;
+    if (trace_path) {
+        if (!trace_buf) TR_HIP(c, hipMalloc(&trace_buf, kTraceCap * 4 * sizeof(unsigned long long)));
+        TR_HIP(c, hipMemsetAsync(trace_buf, 0, kTraceCap * 4 * sizeof(unsigned long long), c->stream));
+        ra.trace = trace_buf;
+        ra.trace_cap = kTraceCap;
+    }
+    int grid_blocks = kRasterBlocks;
+    if (const char* e = std::getenv("TR_RASTER_BLOCKS")) grid_blocks = std::atoi(e);
+    dim3 grid(grid_blocks), block(kRasterThreads);
+    struct TraceDump {
+        tr_context* c; int pass; const char* path; unsigned long long* buf;
+        ~TraceDump() {
+            if (!path) return;
+            std::vector<unsigned long long> h((size_t)kTraceCap * 4);
+            if (hipStreamSynchronize(c->stream) != hipSuccess) return;
+            if (hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+            std::string fn = std::string(path) + (pass ? ".winner" : ".depth");
+            if (FILE* f = std::fopen(fn.c_str(), "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); }
+        }
+    } dump{c, pass, trace_path, trace_buf};
     if (pass == 0) {
         if (c->precheck) hipLaunchKernelGGL((k_raster<0, true>), grid, block, 0, c->stream, ra);
         else hipLaunchKernelGGL((k_raster<0, false>), grid, block, 0, c->stream, ra);
+        if (h_hi / 2u > c->counted_upto) c->counted_upto = h_hi / 2u;
     } else {
         // measured on MI355X (4K african_head): the winner pass is faster without the filter
         // (44 vs 52 us), the depth pass with it (71 vs 93 us)
@@ -296,6 +347,8 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (const char* e = std::getenv("TR_RASTER_MODE")) c->mode = (std::strcmp(e, "tile") == 0 || std::strcmp(e, "1") == 0) ? 1 : 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_SCAN_RECORDS")) c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
     auto bail = [&](int code) {
         tr_destroy(c);
         return code;
@@ -332,6 +385,16 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     }
     if (hipMalloc(&c->nan, sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (const char* e = std::getenv("TR_SHADE_SKIP_CLEAN")) c->skip_clean = std::atoi(e) != 0;
+    c->blocks_x = (width + kShadeBW - 1) / kShadeBW;
+    c->n_blk = (uint32_t)c->blocks_x * (uint32_t)((height + kShadeBH - 1) / kShadeBH);
+    if (hipMalloc(&c->blk_flags, 2 * (size_t)c->n_blk) != hipSuccess) return bail(TR_ERR_OOM);
+    // every block starts "painted": the first resolve writes the whole frame
+    if (hipMemsetAsync(c->blk_flags, 0, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMemsetAsync(c->blk_flags + c->n_blk, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMalloc(&c->chunk_live, kChunkLiveCap) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMemsetAsync(c->chunk_live, 0, kChunkLiveCap, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMalloc(&c->rec, (size_t)(c->rec_cap ? c->rec_cap : 1) * sizeof(ScanRec)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(TR_ERR_HIP);
     if (ensure_tri_capacity(c, 16384) != TR_OK) return bail(TR_ERR_OOM);
     int rc = tr_clear(c);
@@ -347,7 +410,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->state_blk); (void)hipFree(c->nan);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -374,10 +437,12 @@ int tr_clear(tr_context* c) {
         // depth = "no sample yet", winner = none: both all-ones.  Skipped when the last resolve
         // already left the planes cleared (the shade pass wipes what it consumes).
         TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * npix * sizeof(unsigned long long), c->stream));
+        TR_HIP(c, hipMemsetAsync(c->blk_flags, 0, c->n_blk, c->stream));  // "touched" goes with the keys
         c->planes_clean = true;
     }
     c->wkey_dirty = false;
     c->depth_upto = 0;
+    c->counted_upto = 0;
     c->keys_valid = false;
     c->cov_dirty = false;
     c->tri_total = 0;
@@ -597,7 +662,8 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
             ProfScope ps(c, ST_WINNER);
             if (c->wkey_dirty)  // draws were added after a resolve that kept its keys: start the winners over
                 TR_HIP(c, hipMemsetAsync(c->wkey, 0xFF, npix * sizeof(unsigned long long), c->stream));
-            int rc = launch_raster(c, 1, 0u, 2u * c->tri_total);
+            // (that earlier winner pass also consumed the live flags of its chunks: no skipping then)
+            int rc = launch_raster(c, 1, 0u, 2u * c->tri_total, !c->wkey_dirty);
             if (rc != TR_OK) return rc;
             c->keys_valid = true;
             c->wkey_dirty = true;
@@ -653,6 +719,8 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         sa.tiles_x = c->tiles_x;
         sa.W = c->W; sa.H = c->H; sa.out_mask = out_mask; sa.rgba8 = c->rgba8; sa.z_out = c->z_out;
         sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.cov_counters = c->cov_counters;
+        sa.blk_touched = c->blk_flags; sa.blk_painted = c->blk_flags + c->n_blk;
+        sa.skip_clean = (sa.self_clean && c->skip_clean) ? 1 : 0;
         if (c->cov_dirty)  // a second resolve of the same frame: tr_clear zeroes them otherwise
             TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
         c->cov_dirty = true;
@@ -726,21 +794,19 @@ int tr_get_counters(tr_context* c, uint64_t out[8]) {
     std::vector<unsigned long long> tmp(kCounterSlots * 8), cov(kCounterSlots * 8);
     TR_HIP(c, hipMemcpyAsync(tmp.data(), c->counters, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     TR_HIP(c, hipMemcpyAsync(cov.data(), c->cov_counters, cov.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    uint32_t total_scan = 0;
-    TR_HIP(c, hipMemcpyAsync(&total_scan, c->half_off + 2 * (size_t)c->tri_total, sizeof(uint32_t),
-                             hipMemcpyDeviceToHost, c->stream));
     TR_HIP(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 8; ++i) out[i] = 0;
     for (uint32_t s = 0; s < kCounterSlots; ++s) {
         out[0] += tmp[s * 8];
         out[1] += tmp[s * 8 + 1];
+        out[2] += tmp[s * 8 + 2];
         out[5] += tmp[s * 8 + 5];
         out[6] += tmp[s * 8 + 6];
         out[7] += tmp[s * 8 + 7];
         out[4] += cov[s * 8];
     }
     if (!c->resolved) out[4] = 0;
-    out[2] = c->mode == 0 ? total_scan : 0;  // scanlines / samples are only counted by the global raster
+    if (c->mode != 0) out[2] = 0;  // scanlines / samples are only counted by the global raster
     out[3] = c->tri_total;
     if (std::getenv("TR_TILE_DEBUG") && std::atoi(std::getenv("TR_TILE_DEBUG")) == 8) {
         out[2] = tmp[2];

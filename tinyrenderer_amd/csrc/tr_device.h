@@ -18,6 +18,7 @@ constexpr int kKeyTriShift = 36, kKeyHalfShift = 35, kKeyIShift = 18;
 constexpr uint32_t kNanSlots = 8;
 constexpr uint32_t kNanEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kCounterSlots = 1024;  // 64-byte counter slots, summed on read
+constexpr int kShadeBW = 32, kShadeBH = 8;  // pixels per 256-thread shade block: rows of 128 B of RGBA8
 
 struct Mat4 {  // column-major, m[c*4+r] (nalgebra storage order)
     double m[16];
@@ -31,7 +32,9 @@ struct __attribute__((aligned(128))) TriRaster {
     uint32_t res[2];  // resolution of half 0 / half 1 (mod.rs:363-369); 0 = no scanlines
     uint16_t tx0, ty0, tx1, ty1;  // inclusive rect of 16x16 tiles its samples can touch (tx0 > tx1: none)
     uint32_t flags;               // kTriNonFinite: x/y of a point is NaN/inf, no range pruning
-    uint32_t pad[3];
+    uint32_t slot_shift;          // each scanline of this triangle occupies 1 << slot_shift slots of the
+                                  // frame's slot sequence (load balance of the global raster, see k_setup)
+    uint32_t pad[2];
 };
 constexpr uint32_t kTriNonFinite = 1u;
 constexpr int kTile = 16;             // screen tile edge in pixels
@@ -162,5 +165,16 @@ __device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t h
     s.hres = h < 2u ? 2u : h;
     return s;
 }
+
+
+// One slot of the frame's scanline sequence as the raster passes consume it (global raster):
+// A, B - A, 1/hres and the order key of sample 0.  keyh = (tri:28 | half:1 | i:17) << 18 | hres;
+// hres == 0 marks an empty slot (padding, or a scanline too long for the key).
+struct __attribute__((aligned(64))) ScanRec {
+    double ax, ay, az, dx, dy, dz, inv;
+    unsigned long long keyh;
+};
+static_assert(sizeof(ScanRec) == 64, "ScanRec must be 64 B");
+constexpr unsigned long long kRecHresMask = 0x3FFFFull;
 
 }  // namespace tr

@@ -51,7 +51,7 @@ struct SetupArgs {
     Mat4 nmat;             // for the face-normal fallback
     TriRaster* rast;
     TriShade* shade;
-    uint32_t* half_cnt;    // scanlines per half, 2 per triangle (global-atomic raster only)
+    uint32_t* half_cnt;    // slots per half, 2 per triangle (global-atomic raster only)
     uint32_t* tile_cnt;    // triangles per tile (tile raster only)
     int tiles_x, tiles_y;
     int y_lo, y_hi;        // band of pixel rows owned by this context
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     TriRaster R;
     TriShade S;
     R.res[0] = R.res[1] = 0;
-    R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0;
+    R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0; R.slot_shift = 0;
+    R.pad[0] = R.pad[1] = 0;
     if (cull) a.rast[seq] = R;  // the binning pass reads res / rect of every triangle
     if (!cull) {
         // mod.rs:320-327 viewport transform; w of the product is 1 unless inputs are non-finite.
@@ -228,6 +229,17 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
         S.flags = fl;
         R.res[0] = res0;
         R.res[1] = res1;
+        // Load balance of the global raster: a chunk is 64 slots.  A triangle whose scanlines are
+        // long spreads them over 1 << shift slots each (the others stay empty), so that a chunk
+        // holds about the same number of samples whatever the triangle size.  The longest
+        // scanline of either half is S1 -> split; the mean one has about half its samples.
+        if (res0) {
+            double ext = fmax(fabs(R.sp[0] - R.s1[0]), fabs(R.sp[1] - R.s1[1]));
+            double mean_len = ext * 0.5 + 2.0;
+            uint32_t sh = 0;
+            while (sh < 6u && mean_len >= 36.0) { mean_len *= 0.5; ++sh; }  // NaN: stays 0
+            R.slot_shift = sh;
+        }
         // ---- conservative rect of tiles the triangle's samples can land in: every sample lies
         // in the hull of S0,S1,S2,split up to a few ulp; a sample at x lands in column round(x).
         R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0;
@@ -269,9 +281,9 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
             }
         }
     }
-    if (a.mode & 1) {
-        a.half_cnt[2 * (size_t)seq] = res0 ? res0 + 1u : 0u;
-        a.half_cnt[2 * (size_t)seq + 1] = res1 ? res1 + 1u : 0u;
+    if (a.mode & 1) {  // slots per half
+        a.half_cnt[2 * (size_t)seq] = res0 ? (res0 + 1u) << R.slot_shift : 0u;
+        a.half_cnt[2 * (size_t)seq + 1] = res1 ? (res1 + 1u) << R.slot_shift : 0u;
     }
 }
 
@@ -422,69 +434,202 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_small(const uint32_t* __r
 }
 
 // =============================================================== (3) raster
-// One workgroup per chunk of 64 consecutive scanlines of the frame-global scanline sequence.
-// Lanes of wave 0 first own one scanline each (find its half by binary search in half_off, build A and
-// B-A, count its samples), the wave scans the counts, then lanes own SAMPLES: consecutive
-// lanes take consecutive samples of a scanline, i.e. consecutive pixels of a row, so the
-// depth / winner atomics of one wave-instruction fall into contiguous 8-byte slots.
+// The frame's scanlines form one sequence of SLOTS: half h of triangle t owns
+// (res+1) << slot_shift consecutive slots starting at half_off[2t+h]; scanline i sits in slot
+// i << slot_shift of that range, the others are empty.  k_scanlines turns every slot into a
+// 64-byte ScanRec once per draw; the two raster passes then only stream records.
 struct RasterArgs {
-    const uint32_t* half_off;
+    const uint32_t* half_off;   // exclusive prefix of slots per half (+ total at the end)
     const TriRaster* rast;
+    ScanRec* rec;               // records of slots [0, rec_cap); slots beyond are rebuilt on the fly
+    uint32_t rec_cap;
     unsigned long long* depth;  // encoded min depth per pixel, row-major
     unsigned long long* wkey;   // min order key among samples at the min depth
     uint32_t h_lo, h_hi;        // half range [h_lo, h_hi) to enumerate
+    uint32_t count_h;           // samples of halves >= count_h are added to the counters
     int W, H;
     int y_lo, y_hi;             // band of rows owned by this context: [y_lo, y_hi)
     unsigned long long* counters;
     uint32_t* flags;
     NanTable* nan;
+    uint8_t* blk_touched;       // per shade block (32x8 pixels): 1 = a winner key was written into it
+    int blocks_x;
+    uint8_t* chunk_live;        // per 64-slot chunk of the frame: 1 = some sample may be a winner
+    uint32_t live_cap;          // chunks beyond this are always treated as live
+    int use_live;               // winner pass: skip chunks the depth pass found dead
+    int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
+    unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
+                                // ticks, samples | block << 32)
+    uint32_t trace_cap;
 };
 
-constexpr int kRasterThreads = 256;  // wave 0 builds the chunk's scanlines, all 4 waves enumerate samples
+// Record of slot g, which lies in half `lo` (half_off[lo] <= g < half_off[lo + 1]).
+__device__ __forceinline__ ScanRec record_of(const RasterArgs& a, uint32_t lo, uint32_t g) {
+    ScanRec r;
+    r.ax = r.ay = r.az = r.dx = r.dy = r.dz = r.inv = 0.0;
+    r.keyh = 0ull;
+    const uint32_t tri = lo >> 1, half = lo & 1u, s = g - a.half_off[lo];
+    const TriRaster& t = a.rast[tri];
+    const uint32_t sh = t.slot_shift;
+    if (s & ((1u << sh) - 1u)) return r;  // padding slot
+    const uint32_t i = s >> sh;
+    Scanline sl = make_scanline(t, half, i);
+    if (sl.hres > 262143u) {
+        atomicOr(a.flags, 1u << 0);
+        return r;
+    }
+    r.ax = sl.ax; r.ay = sl.ay; r.az = sl.az;
+    r.dx = sl.dx; r.dy = sl.dy; r.dz = sl.dz;
+    r.inv = 1.0 / (double)sl.hres;
+    r.keyh = ((unsigned long long)tri << kKeyTriShift) | ((unsigned long long)half << kKeyHalfShift) |
+             ((unsigned long long)i << kKeyIShift) | (unsigned long long)sl.hres;
+    return r;
+}
 
+// Half holding slot g: the last lo in [lo, hi) with half_off[lo] <= g (given half_off[lo] <= g < half_off[hi]).
+__device__ __forceinline__ uint32_t find_half(const uint32_t* __restrict__ half_off, uint32_t lo, uint32_t hi,
+                                              uint32_t g) {
+    while (hi - lo > 1u) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (half_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// The same search done by one wave with 64 probes per round (3 dependent loads for 10^5 halves
+// instead of 17).  g is wave-uniform; every lane returns the result.
+__device__ __forceinline__ uint32_t find_half_wave(const uint32_t* __restrict__ half_off, uint32_t lo, uint32_t hi,
+                                                   uint32_t g) {
+    const uint32_t lane = threadIdx.x & 63u;
+    while (hi - lo > 1u) {
+        const uint32_t step = (hi - lo + 63u) / 64u;
+        const uint32_t idx = lo + (lane + 1u) * step;  // probes lo+step, lo+2 step, ...
+        const bool le = idx < hi && half_off[idx] <= g;
+        const uint32_t n = (uint32_t)__popcll(__ballot(le));  // monotone: the first n probes hold
+        const uint32_t nlo = lo + n * step;
+        const uint32_t nhi = nlo + step;
+        lo = nlo;
+        hi = nhi < hi ? nhi : hi;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ ScanRec build_record(const RasterArgs& a, uint32_t g) {
+    return record_of(a, find_half(a.half_off, a.h_lo, a.h_hi, g), g);
+}
+
+constexpr int kHalfCache = 256;  // prefix entries a chunk can hold in LDS while it locates its halves
+
+constexpr int kRasterThreads = 256;
+constexpr int kChunkSlots = 64;
+
+
+// One workgroup per chunk of 64 consecutive slots (chunks are aligned to the frame's slot
+// sequence, so both passes and every draw cut it the same way).  The records go to LDS with one
+// 16-byte load per thread; wave 0 scans the sample counts; then lanes own SAMPLES: consecutive
+// lanes take consecutive samples of a scanline, i.e. consecutive pixels of a row, so the
+// depth / winner atomics of one wave-instruction fall into contiguous 8-byte slots.
 template <int PASS, bool PRECHECK>
 __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
-    __shared__ double sA[3][64];
-    __shared__ double sD[3][64];
-    __shared__ double sInv[64];
-    __shared__ unsigned long long sKey[64];
-    __shared__ uint32_t sPre[65];
+    __shared__ uint4 sRec4[kChunkSlots * 4];
+    __shared__ uint32_t sPre[kChunkSlots + 1];
+    __shared__ uint32_t sOff[PASS == 0 ? kHalfCache + 1 : 1];
+    __shared__ uint32_t sEnds[2];
+    const double* sRecD = reinterpret_cast<const double*>(sRec4);
+    const unsigned long long* sRecU = reinterpret_cast<const unsigned long long*>(sRec4);
 
+    // samples a thread keeps in flight: measured on MI355X at 4K, the depth pass (bound by the
+    // atomic rate) is fastest with 1 (58 us; 63 with 2, 68 with 4), the winner pass with 4 (30 vs 31.4)
+    constexpr int kBatch = PASS == 0 ? 1 : 4;
     const int lane = threadIdx.x & 63;
     const bool wave0 = threadIdx.x < 64;
     const uint32_t s_begin = a.half_off[a.h_lo];
     const uint32_t s_end = a.half_off[a.h_hi];
-    const uint32_t n_scan = s_end - s_begin;
-    const uint32_t n_chunks = (n_scan + 63u) / 64u;
-    unsigned long long cnt_samples = 0, cnt_inb = 0;
+    const uint32_t s_count = PASS == 0 ? a.half_off[a.count_h > a.h_lo ? a.count_h : a.h_lo] : 0u;
+    const uint32_t c_lo = s_begin / 64u;
+    const uint32_t c_hi = (uint32_t)(((unsigned long long)s_end + 63ull) / 64ull);
+    unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
     bool nan_active = false;
     if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
 
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        // ---- scanline phase
-        uint32_t g = s_begin + chunk * 64u + (uint32_t)lane;
-        bool valid = wave0 && g < s_end;
+    for (uint32_t chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
+        if (PASS == 1 && chunk < a.live_cap) {
+            // a chunk none of whose samples reached the depth plane's value cannot hold a winner
+            // (a NaN-depth pixel needs every sample that lands on it: no skipping then)
+            const bool dead = a.chunk_live[chunk] == 0;
+            if (dead && a.use_live && !nan_active) continue;
+        }
+        bool any_live = false;
+        unsigned long long tr_t0 = 0, tr_t1 = 0;
+        if (a.trace && threadIdx.x == 0) tr_t0 = wall_clock64();
+        // ---- record phase.  Depth pass: build the chunk's 64 records (two waves locate the halves
+        // of its first and last slot with 64 probes per round, the prefix entries between them go
+        // to LDS, 64 lanes finish their search there), keep them in LDS and store them for the
+        // winner pass.  Winner pass: thread t brings 16 bytes (part t & 3) of slot t >> 2.
+        if (PASS == 0) {
+            const uint32_t g_first = chunk * 64u > s_begin ? chunk * 64u : s_begin;
+            const uint32_t g_last = chunk * 64u + 63u < s_end - 1u ? chunk * 64u + 63u : s_end - 1u;
+            if (g_first > g_last) continue;  // (uniform) the range ends exactly at this chunk's start
+            const int w = threadIdx.x >> 6;
+            if (w < 2) {
+                const uint32_t e = find_half_wave(a.half_off, a.h_lo, a.h_hi, w == 0 ? g_first : g_last);
+                if (lane == 0) sEnds[w] = e;
+            }
+            __syncthreads();
+            const uint32_t e_first = sEnds[0], e_last = sEnds[1];
+            const uint32_t n_e = e_last - e_first + 1u;
+            const bool cached = n_e <= (uint32_t)kHalfCache;
+            if (cached)
+                for (uint32_t t = threadIdx.x; t <= n_e; t += (uint32_t)kRasterThreads) sOff[t] = a.half_off[e_first + t];
+            __syncthreads();
+            if (wave0) {
+                const uint32_t g = chunk * 64u + (uint32_t)lane;
+                ScanRec r;
+                r.ax = r.ay = r.az = r.dx = r.dy = r.dz = r.inv = 0.0;
+                r.keyh = 0ull;
+                if (g >= g_first && g <= g_last) {
+                    uint32_t lo;
+                    if (cached) {
+                        uint32_t l = 0, h = n_e;  // sOff[l] <= g < sOff[h]
+                        while (h - l > 1u) {
+                            uint32_t mid = (l + h) >> 1;
+                            if (sOff[mid] <= g) l = mid; else h = mid;
+                        }
+                        lo = e_first + l;
+                    } else {
+                        lo = find_half(a.half_off, e_first, e_last + 1u, g);
+                    }
+                    r = record_of(a, lo, g);
+                    if (g < a.rec_cap) a.rec[g] = r;
+                    if (lo >= a.count_h && (r.keyh & kRecHresMask)) cnt_scan += 1;
+                }
+                ScanRec* dst = reinterpret_cast<ScanRec*>(sRec4) + lane;
+                *dst = r;
+            }
+        } else {
+            const uint32_t g = chunk * 64u + (threadIdx.x >> 2);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (g >= s_begin && g < s_end) {
+                if (g < a.rec_cap) {
+                    v = reinterpret_cast<const uint4*>(a.rec + g)[threadIdx.x & 3];
+                } else {
+                    const ScanRec r = build_record(a, g);
+                    const int part = threadIdx.x & 3;
+                    const double d0 = part == 0 ? r.ax : part == 1 ? r.az : part == 2 ? r.dy : r.inv;
+                    const unsigned long long u1 = part == 0 ? (unsigned long long)__double_as_longlong(r.ay)
+                                                 : part == 1 ? (unsigned long long)__double_as_longlong(r.dx)
+                                                 : part == 2 ? (unsigned long long)__double_as_longlong(r.dz) : r.keyh;
+                    const unsigned long long u0 = (unsigned long long)__double_as_longlong(d0);
+                    v = make_uint4((uint32_t)u0, (uint32_t)(u0 >> 32), (uint32_t)u1, (uint32_t)(u1 >> 32));
+                }
+            }
+            sRec4[threadIdx.x] = v;
+        }
+        __syncthreads();
         uint32_t cnt = 0;
-        if (valid) {
-            uint32_t lo = a.h_lo, hi = a.h_hi;  // half_off[lo] <= g < half_off[hi]
-            while (hi - lo > 1u) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (a.half_off[mid] <= g) lo = mid; else hi = mid;
-            }
-            uint32_t tri = lo >> 1, half = lo & 1u, i = g - a.half_off[lo];
-            const TriRaster& r = a.rast[tri];
-            Scanline sl = make_scanline(r, half, i);
-            if (sl.hres > 262143u) {
-                atomicOr(a.flags, 1u << 0);
-            } else {
-                cnt = sl.hres + 1u;
-                sA[0][lane] = sl.ax; sA[1][lane] = sl.ay; sA[2][lane] = sl.az;
-                sD[0][lane] = sl.dx; sD[1][lane] = sl.dy; sD[2][lane] = sl.dz;
-                sInv[lane] = 1.0 / (double)sl.hres;
-                sKey[lane] = ((unsigned long long)tri << kKeyTriShift) |
-                             ((unsigned long long)half << kKeyHalfShift) |
-                             ((unsigned long long)i << kKeyIShift);
-            }
+        if (wave0) {
+            const uint32_t h = (uint32_t)(sRecU[lane * 8 + 7] & kRecHresMask);
+            cnt = h ? h + 1u : 0u;
         }
         uint32_t inc = cnt;
 #pragma unroll
@@ -498,71 +643,143 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         }
         __syncthreads();
         const uint32_t total = sPre[64];
+        if (a.trace && threadIdx.x == 0) tr_t1 = wall_clock64();
 
-        // ---- sample phase
-        for (uint32_t k = threadIdx.x; k < total; k += (uint32_t)kRasterThreads) {
-            uint32_t sidx = 0;
+        // ---- sample phase, kBatch samples per thread in flight: the depth-plane loads of a batch
+        // are issued together and waited for once (a wave's wait on a load also waits for the
+        // atomics it issued before it, so one sample at a time costs a full memory round trip
+        // plus an atomic round trip per sample)
+        for (uint32_t k0 = threadIdx.x; k0 < total; k0 += (uint32_t)(kRasterThreads * kBatch)) {
+            uint32_t pix[kBatch], jj[kBatch], sx[kBatch], blk[kBatch];
+            unsigned long long enc[kBatch];
+            int st[kBatch];  // 0: nothing to do, 1: finite depth, 2: NaN depth
 #pragma unroll
-            for (uint32_t step = 32; step; step >>= 1)
-                if (sPre[sidx + step] <= k) sidx += step;
-            uint32_t j = k - sPre[sidx];
-            double sp = (double)j * sInv[sidx];
-            double x = sA[0][sidx] + sp * sD[0][sidx];
-            double y = sA[1][sidx] + sp * sD[1][sidx];
-            double z = sA[2][sidx] + sp * sD[2][sidx];
-            int ix = pixel_coord(x, a.W);
-            int iy = pixel_coord(y, a.H);
-            bool inb = ix >= 0 && iy >= a.y_lo && iy < a.y_hi;
-            if (PASS == 0) {
-                cnt_samples += 1;
-                cnt_inb += inb ? 1 : 0;
-            }
-            if (!inb) continue;
-            double dist = -z;
-            uint32_t pix = (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
-            bool isnan_d = dist != dist;
-            if (PASS == 0) {
-                if (isnan_d) {
-                    bool placed = false;
-                    for (uint32_t s = 0; s < kNanSlots && !placed; ++s) {
-                        uint32_t old = atomicCAS(&a.nan->pix[s], kNanEmpty, pix);
-                        placed = old == kNanEmpty || old == pix;
+            for (int u = 0; u < kBatch; ++u) {
+                const uint32_t k = k0 + (uint32_t)(u * kRasterThreads);
+                st[u] = 0; pix[u] = 0; jj[u] = 0; sx[u] = 0; enc[u] = 0; blk[u] = 0;
+                if (k < total) {
+                    uint32_t sidx = 0;
+#pragma unroll
+                    for (uint32_t step = 32; step; step >>= 1)
+                        if (sPre[sidx + step] <= k) sidx += step;
+                    const uint32_t j = k - sPre[sidx];
+                    const double* r = sRecD + sidx * 8;
+                    const double sp = (double)j * r[6];
+                    const double x = r[0] + sp * r[3];
+                    const double y = r[1] + sp * r[4];
+                    const double z = r[2] + sp * r[5];
+                    const int ix = pixel_coord(x, a.W);
+                    const int iy = pixel_coord(y, a.H);
+                    const bool inb = ix >= 0 && iy >= a.y_lo && iy < a.y_hi;
+                    if (PASS == 0 && chunk * 64u + sidx >= s_count) {
+                        cnt_samples += 1;
+                        cnt_inb += inb ? 1 : 0;
                     }
-                    if (!placed) atomicOr(a.flags, 1u << 5);
+                    if (inb) {
+                        const double dist = -z;
+                        pix[u] = (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+                        jj[u] = j; sx[u] = sidx;
+                        if (PASS == 1) blk[u] = (uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW);
+                        if (dist != dist) {
+                            st[u] = 2;
+                        } else {
+                            st[u] = 1;
+                            enc[u] = encode_depth(dist);
+                            if (PASS == 0 && dist == -__builtin_huge_val()) atomicOr(a.flags, 1u << 3);
+                        }
+                    }
+                }
+            }
+            unsigned long long cur[kBatch];
+            const bool want_load = (PASS == 1 || PRECHECK) && a.debug != 2;
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)  // (lanes with nothing to do read pixel 0: no branch around the load)
+                cur[u] = want_load ? a.depth[st[u] == 1 ? pix[u] : 0u] : 0ull;
+            // every comparison against the loaded values first (one wait), then the atomics, none
+            // of which reads a loaded register: the compiler needs no further wait between them
+            bool act[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (PASS == 0) {
+                    act[u] = st[u] == 1 && (!PRECHECK || enc[u] < cur[u]) && a.debug == 0;
+                    any_live |= st[u] == 2 || (st[u] == 1 && (!PRECHECK || enc[u] <= cur[u]));
                 } else {
-                    if (dist == -__builtin_huge_val()) atomicOr(a.flags, 1u << 3);
-                    unsigned long long e = encode_depth(dist);
-                    if (!PRECHECK || e < a.depth[pix]) atomicMin(&a.depth[pix], e);
+                    act[u] = st[u] == 1 && cur[u] == enc[u];
                 }
-            } else {
-                unsigned long long key = sKey[sidx] | (unsigned long long)j;
-                if (!isnan_d) {
-                    unsigned long long e = encode_depth(dist);
-                    if (a.depth[pix] == e && (!PRECHECK || key < a.wkey[pix])) atomicMin(&a.wkey[pix], key);
+            }
+            bool rare = false;
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                if (PASS == 0) {
+                    if (act[u]) atomicMin(&a.depth[pix[u]], enc[u]);
+                    rare |= st[u] == 2;
+                } else {
+                    const unsigned long long key = (sRecU[sx[u] * 8 + 7] & ~kRecHresMask) | (unsigned long long)jj[u];
+                    if (act[u] && (!PRECHECK || key < a.wkey[pix[u]])) {
+                        atomicMin(&a.wkey[pix[u]], key);
+                        a.blk_touched[blk[u]] = 1;  // the shade pass skips blocks nobody wrote a key into
+                    }
+                    rare |= nan_active && st[u] != 0;
                 }
-                if (nan_active) {
-                    for (uint32_t s = 0; s < kNanSlots; ++s) {
-                        if (a.nan->pix[s] == pix) {
-                            if (isnan_d) atomicMin((unsigned long long*)&a.nan->first_nan[s], key);
-                            else atomicMin((unsigned long long*)&a.nan->first_any[s], key);
+            }
+            if (rare) {  // NaN depths (a degenerate triangle) and the pixels they touched
+#pragma unroll 1
+                for (int u = 0; u < kBatch; ++u) {
+                    // (selects instead of dynamic indexing: the arrays stay in registers)
+                    auto pick = [&](const auto* v) { return u == 0 ? v[0] : u == 1 ? v[kBatch > 1 ? 1 : 0] : u == 2 ? v[kBatch > 2 ? 2 : 0] : v[kBatch - 1]; };
+                    const int stu = pick(st);
+                    const uint32_t pu = pick(pix);
+                    if (stu == 0) continue;
+                    if (PASS == 0) {
+                        if (stu != 2) continue;
+                        bool placed = false;
+                        for (uint32_t s = 0; s < kNanSlots && !placed; ++s) {
+                            uint32_t old = atomicCAS(&a.nan->pix[s], kNanEmpty, pu);
+                            placed = old == kNanEmpty || old == pu;
+                        }
+                        if (!placed) atomicOr(a.flags, 1u << 5);
+                    } else {
+                        const uint32_t su = pick(sx);
+                        const uint32_t ju = pick(jj);
+                        const unsigned long long key = (sRecU[su * 8 + 7] & ~kRecHresMask) | (unsigned long long)ju;
+                        for (uint32_t s = 0; s < kNanSlots; ++s) {
+                            if (a.nan->pix[s] == pu) {
+                                if (stu == 2) atomicMin((unsigned long long*)&a.nan->first_nan[s], key);
+                                else atomicMin((unsigned long long*)&a.nan->first_any[s], key);
+                            }
                         }
                     }
                 }
             }
         }
-        __syncthreads();  // LDS is rewritten by the next chunk
+        // (also the barrier before the next chunk rewrites LDS)
+        const int live = __syncthreads_or(any_live ? 1 : 0);
+        if (a.trace && threadIdx.x == 0 && chunk - c_lo < a.trace_cap) {
+            unsigned long long* t = a.trace + 4 * (size_t)(chunk - c_lo);
+            t[0] = tr_t0; t[1] = tr_t1; t[2] = wall_clock64();
+            t[3] = (unsigned long long)total | ((unsigned long long)blockIdx.x << 32);
+        }
+        if (threadIdx.x == 0 && chunk < a.live_cap) {
+            if (PASS == 0) {
+                if (live) a.chunk_live[chunk] = 1;
+            } else {
+                a.chunk_live[chunk] = 0;  // consumed: the next frame starts from zeros
+            }
+        }
     }
     if (PASS == 0) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
             cnt_samples += __shfl_down(cnt_samples, d, 64);
             cnt_inb += __shfl_down(cnt_inb, d, 64);
+            cnt_scan += __shfl_down(cnt_scan, d, 64);
         }
-        if (lane == 0 && cnt_samples) {
+        if (lane == 0 && (cnt_samples | cnt_scan)) {
             // one 64-byte slot per block (mod kCounterSlots): same-address atomics serialise
             unsigned long long* slot = a.counters + (size_t)(blockIdx.x % kCounterSlots) * 8;
             atomicAdd(&slot[0], cnt_samples);
             atomicAdd(&slot[1], cnt_inb);
+            if (cnt_scan) atomicAdd(&slot[2], cnt_scan);
         }
     }
 }
@@ -592,6 +809,9 @@ struct ShadeArgs {
     double* rgba_f64;   // optional, 4 per pixel
     uint32_t* flags;
     unsigned long long* cov_counters;  // kCounterSlots x 8, [0] of each slot used
+    uint8_t* blk_touched;  // per 32x8 block: the winner pass wrote a key into it this frame
+    uint8_t* blk_painted;  // per block: rgba8 holds something other than the background
+    int skip_clean;        // blocks neither touched nor painted are left alone (RGBA8-only resolve, global raster)
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -636,13 +856,25 @@ __device__ __forceinline__ uint32_t f64_as_u8(double v) {
     return (uint32_t)v;
 }
 
-constexpr int kShadeBW = 32, kShadeBH = 8;  // pixels per 256-thread block: rows of 128 B of RGBA8
 
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const int x = blockIdx.x * kShadeBW + (threadIdx.x & (kShadeBW - 1));
     const int y = blockIdx.y * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
     const uint32_t pix = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+    const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
+    if (a.skip_clean) {
+        // Nothing landed in this block: its keys are all "none".  If the previous frame left it
+        // at the background colour too there is nothing to do; otherwise repaint the background.
+        // (A NaN-depth winner is written outside the winner pass: no skipping in such a frame.)
+        const bool touched = a.blk_touched[blk] != 0 || a.nan->pix[0] != kNanEmpty;
+        if (!touched) {
+            if (a.blk_painted[blk] == 0) return;
+            if (live) a.rgba8[pix] = 0xFF000000u;  // BLACK, helpers/mod.rs:22
+            if (threadIdx.x == 0) a.blk_painted[blk] = 0;
+            return;
+        }
+    }
     bool listed = live;
     if (a.tile_off && live) {
         int tile = (y / kTile) * a.tiles_x + (x / kTile);
@@ -661,6 +893,13 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     unsigned long long nwin = __popcll(__ballot(has));
     if ((threadIdx.x & 63) == 0 && nwin)
         atomicAdd(&a.cov_counters[(size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8], nwin);
+    {
+        const int any = __syncthreads_or(has ? 1 : 0);
+        if (threadIdx.x == 0) {
+            a.blk_painted[blk] = any ? 1 : 0;
+            if (a.self_clean) a.blk_touched[blk] = 0;
+        }
+    }
     if (!live) return;
     double col[4] = {0.0, 0.0, 0.0, 255.0};  // BLACK, helpers/mod.rs:22
     double zval = -__builtin_huge_val();
