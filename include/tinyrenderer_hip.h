@@ -62,8 +62,10 @@ enum {
 /* Raster strategies (same results, bit for bit). */
 enum {
     TR_RASTER_GLOBAL = 0, /* default: samples enumerated frame-wide, 64-bit atomicMin on HBM planes */
-    TR_RASTER_TILE = 1    /* triangles binned to 16x16 tiles, depth/winner tiles in LDS;
+    TR_RASTER_TILE = 1,   /* triangles binned to 16x16 tiles, depth/winner tiles in LDS;
                              env TR_RASTER_MODE=tile selects it at tr_create */
+    TR_RASTER_ROWS = 2    /* scanlines binned by (pixel row, 256-pixel segment), one wave per bin with
+                             its planes in LDS, no global atomics; env TR_RASTER_MODE=rows */
 };
 
 /* Buffer layouts for the tr_read_* calls. */
@@ -145,7 +147,7 @@ int tr_read_rgba_f64(tr_context* ctx, double* out, int layout);
 /* Counters since tr_clear: [1] in-bounds z-tested samples ("fragments",
  * src/model_renderer/mod.rs:380-389; valid after tr_resolve in tile mode), [3] triangles
  * submitted, [4] pixels with a winner (valid after tr_resolve); [0] samples enumerated and
- * [2] scanlines are only counted by TR_RASTER_GLOBAL (0 otherwise); [5..7] reserved. */
+ * [2] scanlines are not counted by TR_RASTER_TILE (0 there); [5..7] reserved. */
 int tr_get_counters(tr_context* ctx, uint64_t out[8]);
 int tr_get_status_flags(tr_context* ctx, uint32_t* out_flags);
 

@@ -22,7 +22,7 @@ def _head_scene(W, H, rot=0.025, eye=(0.0, 0.0, 2.0), with_eye=False):
     return draws
 
 
-MODES = [pytest.param(1, id="tile"), pytest.param(0, id="global")]
+MODES = [pytest.param(1, id="tile"), pytest.param(0, id="global"), pytest.param(2, id="rows")]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -33,7 +33,7 @@ def test_head_small(oracle, W, H, mode):
     g = SU.gpu_render(W, H, draws, mode=mode)
     info = SU.assert_parity(o, g)
     assert g["counters"]["fragments"] == o["counters"]["fragments"]
-    if mode == 0:  # only the global raster enumerates (and counts) out-of-bounds samples
+    if mode != 1:  # the tile raster does not enumerate (or count) out-of-bounds samples
         assert g["counters"]["samples"] == o["counters"]["samples"]
         assert g["counters"]["scanlines"] == o["counters"]["scanlines"]
     assert info["f64_colour_mismatches"] == 0
@@ -155,7 +155,7 @@ def test_nan_depth_degenerate_triangle(oracle):
     d, b = _synthetic_component(degenerate), _synthetic_component(big)
     sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
     for order in ((d, b), (b, d)):
-        for mode in (1, 0):
+        for mode in (2, 1, 0):
             for W, Hh in ((16, 16), (50, 37)):
                 draws = [(mc, sh) for mc in order]
                 o = SU.oracle_render(oracle, W, Hh, draws)
@@ -180,11 +180,11 @@ def test_offscreen_and_culled(oracle):
     sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
     o = SU.oracle_render(oracle, 120, 90, [(mc, sh)])
     assert o["counters"]["culled"] == 1
-    for mode in (1, 0):
+    for mode in (2, 1, 0):
         g = SU.gpu_render(120, 90, [(mc, sh)], mode=mode)
         SU.assert_parity(o, g)
         assert g["counters"]["fragments"] == o["counters"]["fragments"] < o["counters"]["samples"]
-        if mode == 0:
+        if mode != 1:
             assert g["counters"]["samples"] == o["counters"]["samples"]
 
 
@@ -235,7 +235,7 @@ def test_fuzz_random_triangles(oracle, seed, n_tris, W, H):
     rng = np.random.default_rng(seed)
     draws = _random_scene(rng, n_tris, W, H)
     o = SU.oracle_render(oracle, W, H, draws)
-    for mode in (1, 0):
+    for mode in (2, 1, 0):
         g = SU.gpu_render(W, H, draws, mode=mode)
         info = SU.assert_parity(o, g)
         assert g["counters"]["fragments"] == o["counters"]["fragments"]
@@ -402,7 +402,7 @@ def test_large_and_tiny_triangles_mixed(oracle, mode):
     g = SU.gpu_render(W, Hh, draws, mode=mode)
     info = SU.assert_parity(o, g)
     assert info["f64_colour_mismatches"] == 0 and info["covered"] > 10000
-    if mode == 0:
+    if mode != 1:
         for k in ("samples", "fragments", "scanlines"):
             assert g["counters"][k] == o["counters"][k], k
 
@@ -436,3 +436,21 @@ def test_background_blocks_are_repainted_between_frames(oracle):
     finally:
         st.close()
         eye_mc.parent = head
+
+
+def test_row_raster_grows_its_buffers(oracle, monkeypatch):
+    """Row raster: a record buffer or bin list that is too small raises TR_FLAG_BIN_OVERFLOW on the
+    device; the next synchronising call grows it and redoes the resolve."""
+    W, Hh = 400, 300
+    draws = _head_scene(W, Hh, with_eye=True)
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    for env in ({"TR_SCAN_RECORDS": "1000"}, {"TR_ROW_REFS": "500"}, {"TR_SCAN_RECORDS": "1", "TR_ROW_REFS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = SU.gpu_render(W, Hh, draws, mode=2)
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], (env, k)
+        for k in env:
+            monkeypatch.delenv(k)

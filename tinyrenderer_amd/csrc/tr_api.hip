@@ -4,6 +4,7 @@
 #include "../../include/tinyrenderer_hip.h"
 #include "tr_kernels.hip"
 #include "tr_tile.hip"
+#include "tr_rows.hip"
 
 #include <cmath>
 #include <cstdio>
@@ -57,6 +58,14 @@ struct tr_context {
     ScanRec* rec = nullptr;          // scanline records of the frame's first rec_cap slots
     uint32_t rec_cap = 1u << 20;     // 64 MB; slots beyond are rebuilt by every raster pass (TR_SCAN_RECORDS)
     uint8_t* chunk_live = nullptr;
+    // row raster (mode 2)
+    uint32_t* bin_cnt = nullptr;
+    uint32_t* bin_off = nullptr;
+    uint32_t* bin_list = nullptr;
+    uint32_t* refs = nullptr;
+    uint32_t n_bins_padded = 0;
+    uint32_t ref_cap = 2u << 20;
+    int nseg = 0;
     uint8_t* blk_flags = nullptr;    // [0, n_blk): touched this frame, [n_blk, 2 n_blk): rgba8 not background
     uint32_t n_blk = 0;
     int blocks_x = 0;
@@ -193,6 +202,8 @@ int ensure_scratch(tr_context* c, double** p, size_t* cap, size_t need) {
 }
 
 constexpr int kRasterBlocks = 4096;
+constexpr int kRowBinBlocks = 1024;
+constexpr int kRowGrid = 256 * 15;  // waves: 15 per CU fit the LDS (10.3 KB each)
 constexpr uint32_t kChunkLiveCap = 1u << 20;  // 64 M slots per frame get dead-chunk skipping
 
 void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_hi) {
@@ -267,7 +278,64 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
 
 // Tile mode: the (tile, triangle) pair list has a fixed capacity; if a frame needs more, the
 // device raises bit 6, and the next host-synchronising call grows the list and redoes the resolve.
+int settle_row_overflow(tr_context* c) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        uint32_t fl = 0;
+        TR_HIP(c, hipMemcpyAsync(&fl, c->flags, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+        TR_HIP(c, hipStreamSynchronize(c->stream));
+        if (!(fl & (1u << 6))) return TR_OK;
+        uint32_t slots = 0, refs = 0;
+        TR_HIP(c, hipMemcpy(&slots, c->half_off + 2 * (size_t)c->tri_total, sizeof(slots), hipMemcpyDeviceToHost));
+        bool fallback = false;
+        if (slots > c->rec_cap) {
+            uint64_t cap = (uint64_t)slots + slots / 4 + 1024;
+            if (cap * sizeof(ScanRec) > (8ull << 30)) {
+                fallback = true;
+            } else {
+                (void)hipFree(c->rec);
+                c->rec = nullptr;
+                TR_HIP(c, hipMalloc(&c->rec, cap * sizeof(ScanRec)));
+                c->rec_cap = (uint32_t)cap;
+            }
+        } else {
+            TR_HIP(c, hipMemcpy(&refs, c->bin_off + c->n_bins_padded, sizeof(refs), hipMemcpyDeviceToHost));
+            uint64_t cap = (uint64_t)refs + refs / 4 + 1024;
+            if (cap > (1ull << 30)) {
+                fallback = true;
+            } else {
+                (void)hipFree(c->refs);
+                c->refs = nullptr;
+                TR_HIP(c, hipMalloc(&c->refs, cap * sizeof(uint32_t)));
+                c->ref_cap = (uint32_t)cap;
+            }
+        }
+        fl &= ~(1u << 6);
+        TR_HIP(c, hipMemcpy(c->flags, &fl, sizeof(fl), hipMemcpyHostToDevice));
+        TR_HIP(c, hipMemsetAsync(c->bin_cnt, 0, (size_t)c->n_bins_padded * sizeof(uint32_t), c->stream));
+        TR_HIP(c, hipMemsetAsync(c->counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
+        uint32_t mask = c->resolved_mask;
+        c->resolved = false;
+        c->keys_valid = false;
+        if (fallback) {
+            // scanlines that sweep the whole frame (huge or non-finite coordinates) in numbers no bin
+            // list should hold: this context continues with the global-atomic raster
+            c->mode = 0;
+            c->depth_upto = 0;
+            c->counted_upto = 0;
+            c->wkey_dirty = false;
+            TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * (size_t)c->W * c->H * sizeof(unsigned long long), c->stream));
+            TR_HIP(c, hipMemsetAsync(c->blk_flags, 0, c->n_blk, c->stream));
+            // k_clear_state's job for the NaN table was done at tr_clear; the row raster never touched it
+        }
+        int rc = tr_resolve(c, mask);
+        if (rc != TR_OK) return rc;
+        if (fallback) return TR_OK;
+    }
+    return fail(c, TR_ERR_UNSUPPORTED, "row bin list kept overflowing");
+}
+
 int settle_bin_overflow(tr_context* c) {
+    if (c->mode == 2 && c->resolved) return settle_row_overflow(c);
     if (c->mode != 1 || !c->resolved) return TR_OK;
     for (int attempt = 0; attempt < 4; ++attempt) {
         uint32_t fl = 0;
@@ -344,11 +412,15 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     c->H = height;
     c->y_lo = 0;
     c->y_hi = height;
-    if (const char* e = std::getenv("TR_RASTER_MODE")) c->mode = (std::strcmp(e, "tile") == 0 || std::strcmp(e, "1") == 0) ? 1 : 0;
+    if (const char* e = std::getenv("TR_RASTER_MODE"))
+        c->mode = (std::strcmp(e, "tile") == 0 || std::strcmp(e, "1") == 0) ? 1
+                  : (std::strcmp(e, "rows") == 0 || std::strcmp(e, "2") == 0) ? 2 : 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SCAN_RECORDS")) c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TR_ROW_REFS")) c->ref_cap = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (c->ref_cap < 1) c->ref_cap = 1;
     auto bail = [&](int code) {
         tr_destroy(c);
         return code;
@@ -385,6 +457,17 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     }
     if (hipMalloc(&c->nan, sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
+    {
+        c->nseg = (width + kSegW - 1) / kSegW;
+        const size_t n_bins = (size_t)c->nseg * height;
+        const size_t quantum = 4 * (size_t)kTileScanThreads;
+        c->n_bins_padded = (uint32_t)((n_bins + quantum - 1) / quantum * quantum);
+        if (hipMalloc(&c->bin_cnt, (size_t)c->n_bins_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->bin_off, ((size_t)c->n_bins_padded + 4) * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->bin_list, (size_t)c->n_bins_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMalloc(&c->refs, (size_t)c->ref_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+        if (hipMemsetAsync(c->bin_cnt, 0, (size_t)c->n_bins_padded * sizeof(uint32_t), c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    }
     if (const char* e = std::getenv("TR_SHADE_SKIP_CLEAN")) c->skip_clean = std::atoi(e) != 0;
     c->blocks_x = (width + kShadeBW - 1) / kShadeBW;
     c->n_blk = (uint32_t)c->blocks_x * (uint32_t)((height + kShadeBH - 1) / kShadeBH);
@@ -410,7 +493,8 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags);
+    (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->state_blk); (void)hipFree(c->nan);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -585,7 +669,7 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
         sa.nmat = nmat;
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
-        sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;
+        sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;  // (the row raster uses the global raster's slot sequence)
         DrawDev& d = sa.params;
         std::memset(&d, 0, sizeof(d));
         d.tex = p->diffuse ? p->diffuse->dev : nullptr;
@@ -607,7 +691,7 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
         sa.draw_table = c->draw_table;
         hipLaunchKernelGGL(k_setup, dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
-        if (c->mode == 0) {
+        if (c->mode != 1) {
             // prefix of scanline counts, continuing from the previous draw's total
             const uint32_t lo = 2u * tri_base;
             uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
@@ -669,6 +753,52 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
             c->wkey_dirty = true;
         }
     }
+    if (c->tri_total && c->mode == 2 && !c->keys_valid) {
+        RowArgs ra;
+        ra.half_off = c->half_off; ra.rast = c->rast; ra.n_half = 2u * c->tri_total;
+        ra.rec = c->rec; ra.rec_cap = c->rec_cap;
+        ra.bin_cnt = c->bin_cnt; ra.bin_off = c->bin_off; ra.bin_list = c->bin_list; ra.n_padded = c->n_bins_padded;
+        ra.refs = c->refs; ra.ref_cap = c->ref_cap;
+        ra.wkey = c->wkey; ra.blk_touched = c->blk_flags; ra.blocks_x = c->blocks_x;
+        ra.W = c->W; ra.H = c->H; ra.nseg = c->nseg; ra.y_lo = c->y_lo; ra.y_hi = c->y_hi;
+        ra.counters = c->counters; ra.flags = c->flags;
+        ra.trace = nullptr; ra.trace_cap = 0;
+        if (c->resolved)  // a second raster of the same frame (more draws, or more planes): count afresh
+            TR_HIP(c, hipMemsetAsync(c->counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
+        {
+            ProfScope ps(c, ST_DEPTH);  // stage slot 3 = records + binning in row mode
+            hipLaunchKernelGGL((k_row_bin<false>), dim3(kRowBinBlocks), dim3(256), 0, c->stream, ra);
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileScanThreads), 0, c->stream, c->bin_cnt, c->bin_off,
+                               c->bin_list, (uint32_t)(c->nseg * c->H), c->n_bins_padded, c->ref_cap, c->flags);
+            hipLaunchKernelGGL((k_row_bin<true>), dim3(kRowBinBlocks), dim3(256), 0, c->stream, ra);
+            TR_HIP(c, hipGetLastError());
+        }
+        {
+            ProfScope ps(c, ST_WINNER);  // stage slot 4 = row raster
+            int grid = kRowGrid;
+            if (const char* e = std::getenv("TR_ROW_GRID")) grid = std::atoi(e);
+            ra.trace = nullptr; ra.trace_cap = 0;
+            static const char* trace_path = std::getenv("TR_RASTER_TRACE");
+            static unsigned long long* trace_buf = nullptr;
+            constexpr uint32_t kTraceCap = 1u << 16;
+            if (trace_path) {
+                if (!trace_buf) TR_HIP(c, hipMalloc(&trace_buf, kTraceCap * 4 * sizeof(unsigned long long)));
+                TR_HIP(c, hipMemsetAsync(trace_buf, 0, kTraceCap * 4 * sizeof(unsigned long long), c->stream));
+                ra.trace = trace_buf; ra.trace_cap = kTraceCap;
+            }
+            hipLaunchKernelGGL(k_row_raster, dim3(grid), dim3(kRowThreads), 0, c->stream, ra);
+            TR_HIP(c, hipGetLastError());
+            if (trace_path) {
+                std::vector<unsigned long long> h((size_t)kTraceCap * 4);
+                TR_HIP(c, hipStreamSynchronize(c->stream));
+                TR_HIP(c, hipMemcpy(h.data(), trace_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                std::string fn = std::string(trace_path) + ".rows";
+                if (FILE* f = std::fopen(fn.c_str(), "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); }
+            }
+        }
+        c->keys_valid = true;
+        c->planes_clean = false;
+    }
     if (!c->resolved && c->mode == 1) {
         const uint32_t n_tiles = (uint32_t)(c->tiles_x * c->tiles_y);
         {
@@ -710,9 +840,9 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
     {
         ProfScope ps(c, ST_SHADE);
         ShadeArgs sa;
-        sa.wkey = c->wkey; sa.depth = c->depth; sa.key_out = c->key_out;
+        sa.wkey = c->wkey; sa.depth = c->mode == 0 ? c->depth : nullptr; sa.key_out = c->key_out;
         // the cheap path (RGBA8 only) leaves the planes cleared so the next tr_clear is free
-        sa.self_clean = (c->mode == 0 && out_mask == TR_OUT_RGBA8) ? 1 : 0;
+        sa.self_clean = (c->mode != 1 && out_mask == TR_OUT_RGBA8) ? 1 : 0;
         sa.rast = c->rast; sa.shade = c->shade; sa.draws = c->draw_table;
         sa.nan = c->mode == 0 ? c->nan : nullptr;
         sa.tile_off = c->mode == 1 ? c->tile_off : nullptr;
@@ -728,7 +858,7 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
                            0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }
-    if (c->mode == 0 && out_mask == TR_OUT_RGBA8) {
+    if (c->mode != 1 && out_mask == TR_OUT_RGBA8) {
         c->planes_clean = true;
         c->depth_upto = 0;
         c->keys_valid = false;
@@ -806,7 +936,7 @@ int tr_get_counters(tr_context* c, uint64_t out[8]) {
         out[4] += cov[s * 8];
     }
     if (!c->resolved) out[4] = 0;
-    if (c->mode != 0) out[2] = 0;  // scanlines / samples are only counted by the global raster
+    if (c->mode == 1) out[2] = 0;  // scanlines / samples are not counted by the tile raster
     out[3] = c->tri_total;
     if (std::getenv("TR_TILE_DEBUG") && std::atoi(std::getenv("TR_TILE_DEBUG")) == 8) {
         out[2] = tmp[2];
@@ -857,11 +987,12 @@ int tr_set_band(tr_context* c, int y_lo, int y_hi) {
 }
 
 int tr_set_raster_mode(tr_context* c, int mode) {
-    if (!c || (mode != 0 && mode != 1)) return TR_ERR_INVALID;
+    if (!c || mode < 0 || mode > 2) return TR_ERR_INVALID;
     if (c->tri_total) return fail(c, TR_ERR_INVALID, "tr_set_raster_mode must follow tr_clear, before any draw");
     if (mode != c->mode) {
         c->mode = mode;
-        return tr_clear(c);  // the two modes clear different state
+        c->planes_clean = false;  // the modes leave different things in the planes
+        return tr_clear(c);
     }
     return TR_OK;
 }

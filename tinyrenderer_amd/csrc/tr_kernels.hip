@@ -867,7 +867,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         // Nothing landed in this block: its keys are all "none".  If the previous frame left it
         // at the background colour too there is nothing to do; otherwise repaint the background.
         // (A NaN-depth winner is written outside the winner pass: no skipping in such a frame.)
-        const bool touched = a.blk_touched[blk] != 0 || a.nan->pix[0] != kNanEmpty;
+        const bool touched = a.blk_touched[blk] != 0 || (a.nan && a.nan->pix[0] != kNanEmpty);
         if (!touched) {
             if (a.blk_painted[blk] == 0) return;
             if (live) a.rgba8[pix] = 0xFF000000u;  // BLACK, helpers/mod.rs:22
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     unsigned long long key = listed ? a.wkey[pix] : kKeyNone;
     if (a.self_clean && key != kKeyNone) {  // leave the planes cleared for the next frame
         a.wkey[pix] = kKeyNone;
-        a.depth[pix] = kKeyNone;
+        if (a.depth) a.depth[pix] = kKeyNone;
     }
     if (a.nan && live && a.nan->pix[0] != kNanEmpty) {
         for (uint32_t s = 0; s < kNanSlots; ++s)

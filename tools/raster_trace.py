@@ -25,6 +25,7 @@ def summarise(path):
     print(f"== {path}: {len(t)} chunks, {n.sum()} samples, span {e.max():.1f} us")
     print(f"   record phase   us: mean {np.mean(s - b):.2f} p50 {np.median(s - b):.2f} p99 {np.percentile(s - b, 99):.2f} max {np.max(s - b):.2f}")
     print(f"   sample phase  us: mean {np.mean(e - s):.2f} p50 {np.median(e - s):.2f} p99 {np.percentile(e - s, 99):.2f} max {np.max(e - s):.2f}")
+    recs = blk  # (row raster: records of the bin in the high word)
     it = np.maximum(1, (n + 255) // 256)
     print(f"   us per 256-sample iteration: mean {np.mean((e - s) / it):.3f} p50 {np.median((e - s) / it):.3f}")
     print(f"   chunk begin us: p50 {np.median(b):.1f} p90 {np.percentile(b, 90):.1f} max {b.max():.1f}; end: p50 {np.median(e):.1f} p90 {np.percentile(e, 90):.1f} p99 {np.percentile(e, 99):.1f}")
@@ -43,6 +44,9 @@ def main():
     from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
 
     draws = bench.build_scene(W, H)
+    for suffix in (".depth", ".winner", ".rows"):
+        if os.path.exists(path + suffix):
+            os.remove(path + suffix)
     st = ModelRendererState(W, H)
     for _ in range(4):
         clear_screen(st)
@@ -51,8 +55,9 @@ def main():
         st.resolve()
     st.synchronize()
     st.close()
-    for suffix in (".depth", ".winner"):
-        summarise(path + suffix)
+    for suffix in (".depth", ".winner", ".rows"):
+        if os.path.exists(path + suffix):
+            summarise(path + suffix)
 
 
 if __name__ == "__main__":
