@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun) from the repo root: kernel-time statistics and HBM / VALU
+# counters of the bench command, each counter set in a run of its own (rocprofv3 does not split
+# counters over passes).  Output under gpurun_out/prof/; tools/summarise_profiles.py turns it into
+# the files committed under profiles/.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof
+rm -rf "$OUT" && mkdir -p "$OUT"
+BENCH="python3 bench.py --contexts 1 --steps 40 --warmup 5 --no-cpu-baseline --profile-frames 0"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o ks -- $BENCH > "$OUT/stats.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o pmc -- $BENCH > "$OUT/fetch.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- $BENCH > "$OUT/write.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d "$OUT/sq" -o pmc -- $BENCH > "$OUT/sq.log" 2>&1
+timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/tcc" -o pmc -- $BENCH > "$OUT/tcc.log" 2>&1
+# the headline command itself (two contexts), for the committed bench line
+timeout -k 10 300 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+ls -R "$OUT" | head -40

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof (tools/collect_profiles.sh) -> profiles/<tag>_kernel_stats_4k.csv,
+profiles/<tag>_hbm_pmc_4k.json, profiles/<tag>_bench_4k.json."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = "gpurun_out/prof"
+os.makedirs("profiles", exist_ok=True)
+
+
+def counters(sub):
+    """mean counter value per launch, per kernel (short name)"""
+    out = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            out[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in out.items()}
+
+
+stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats_4k.csv")
+pmc = {"source": "tools/collect_profiles.sh: rocprofv3 --pmc, one counter set per run, python3 bench.py --contexts 1 "
+                 "--steps 40 --warmup 5, african_head 3840x2160, global raster, RGBA8-only resolve",
+       "units": "FETCH_SIZE / WRITE_SIZE in KB per launch as rocprofv3 reports them, averaged over launches",
+       "gfx950_correction": "FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section): doubled; WRITE_SIZE as is",
+       "workload": {"W": 3840, "H": 2160, "scene": "african_head"}, "kernels": {}}
+sets = {s: counters(s) for s in ("fetch", "write", "sq", "tcc")}
+names = set()
+for s in sets.values():
+    names |= set(s)
+for k in sorted(names):
+    e = {}
+    for s in sets.values():
+        e.update(s.get(k, {}))
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        e["hbm_bytes_per_launch"] = int(2 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024)
+    pmc["kernels"][k] = e
+sh = pmc["kernels"].get("tr::k_shade", {})
+if "hbm_bytes_per_launch" in sh:
+    pmc["k_shade_hbm_bytes_per_launch"] = sh["hbm_bytes_per_launch"]
+json.dump(pmc, open(f"profiles/{tag}_hbm_pmc_4k.json", "w"), indent=1)
+b = os.path.join(src, "bench.json")
+if os.path.exists(b):
+    lines = [l for l in open(b) if l.startswith("{")]
+    if lines:
+        open(f"profiles/{tag}_bench_4k.json", "w").write(lines[-1])
+print(json.dumps(pmc, indent=1)[:3000])
