@@ -1,0 +1,188 @@
+// Host side of the drop-in, C++17, header only: the reference's `model_renderer` module
+// (/root/reference/src/model_renderer/mod.rs) over the C ABI of include/tinyrenderer_hip.h.
+// `ModelRendererState`, `clear_screen`, `render_mesh_component`, `MeshComponent` and `Transform`
+// keep the reference's names and call shape.  The two shader closures of render_mesh_component
+// (mod.rs:225-230: host code, cannot run on a GPU) are replaced by `BuiltinShader`, the values the
+// one closure pair the reference ships captures (src/main.rs:118-267).  Nothing here computes
+// pixels: every call ends in the library, and without a gfx950 GPU construction throws.
+#pragma once
+#include <map>
+#include <memory>
+
+#include "helpers.hpp"
+
+namespace tinyrenderer {
+
+struct RendererError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// src/model_renderer/mod.rs:21-27,87-148 (the Cell<> fields become plain members)
+class Transform {
+  public:
+    Vector3 position() const { return position_; }
+    Vector3 rotation() const { return rotation_; }
+    Vector3 scale() const { return scale_; }
+    Matrix4 matrix() const { return matrix_; }
+    void set_position(const Vector3& p) {  // mod.rs:118-125: pokes m14 / m24 / m34 only, no resync
+        position_ = p;
+        matrix_.at(0, 3) = p.x; matrix_.at(1, 3) = p.y; matrix_.at(2, 3) = p.z;
+    }
+    void set_rotation(const Vector3& r) { rotation_ = r; resync_matrix(); }
+    void set_scale(const Vector3& s) { scale_ = s; resync_matrix(); }
+
+  private:
+    void resync_matrix() {  // mod.rs:140-147: T * R * S, left-associative
+        matrix_ = make_translation_matrix(position_) * make_rotation_matrix(rotation_.x, rotation_.y, rotation_.z) *
+                  make_scale_matrix(scale_);
+    }
+    Vector3 position_{0.0, 0.0, 0.0}, rotation_{0.0, 0.0, 0.0}, scale_{1.0, 1.0, 1.0};
+    Matrix4 matrix_ = Matrix4::identity();
+};
+
+// src/model_renderer/mod.rs:12-19,37-85.  texture / normal_map are held already flipped
+// vertically, like the reference's flip_vertically(load_nd_rgba_img_from_file(..)).
+struct MeshComponent {
+    Object mesh;
+    Transform transform;
+    RgbaImage texture, normal_map;
+    const MeshComponent* parent = nullptr;
+
+    MeshComponent() = default;
+    MeshComponent(Object obj, RgbaImage tex, RgbaImage nm) : mesh(std::move(obj)), texture(std::move(tex)), normal_map(std::move(nm)) {}
+    // MeshComponent::from((obj_path, texture_path, normal_map_path)), mod.rs:37-50
+    static MeshComponent from(const std::string& obj_path, const std::string& texture_path, const std::string& normal_map_path) {
+        return MeshComponent(load_model(obj_path), load_rgba_img_from_file(texture_path, /*flipped=*/true),
+                             load_rgba_img_from_file(normal_map_path, /*flipped=*/true));
+    }
+    // mod.rs:67-84: fold identity * self * parent * grandparent ...
+    Matrix4 local_to_world_matrix() const {
+        Matrix4 acc = Matrix4::identity();
+        for (const MeshComponent* c = this; c; c = c->parent) acc = acc * c->transform.matrix();
+        return acc;
+    }
+};
+
+// What the vertex + fragment closures of src/main.rs:146-267 capture.
+struct BuiltinShader {
+    Matrix4 perspective_matrix, model_view_matrix, inverse_model_view_matrix;
+    Vector3 camera_pos;
+    bool use_normal_map = true;         // main.rs:182
+    double light_intensity = 1.0;       // main.rs:254
+    double ambient_light = 1.0;         // main.rs:255
+    Color vertex_color = WHITE;         // main.rs:170
+    // main.rs:126-135: normal matrix = model_view.transpose().try_inverse() or identity
+    static BuiltinShader make(const Matrix4& perspective, const Matrix4& model_view, const Vector3& camera_pos) {
+        BuiltinShader s;
+        s.perspective_matrix = perspective;
+        s.model_view_matrix = model_view;
+        auto inv = model_view.transpose().try_inverse();
+        s.inverse_model_view_matrix = inv ? *inv : Matrix4::identity();
+        s.camera_pos = camera_pos;
+        return s;
+    }
+};
+
+// src/model_renderer/mod.rs:29-35,150-173.  The buffers live on the GPU; the accessors read them
+// back in the reference's layout (Array3<f64> of shape (W, H, C), x the slow axis).
+class ModelRendererState {
+  public:
+    ModelRendererState(size_t frame_width, size_t frame_height, int device = 0) : w_(frame_width), h_(frame_height) {
+        const int rc = tr_create(device, (int)frame_width, (int)frame_height, &ctx_);
+        if (rc != TR_OK)
+            throw RendererError("ModelRendererState::new: tr_create failed (" + std::to_string(rc) +
+                                "); a gfx950 GPU is required, there is no CPU fallback");
+    }
+    ~ModelRendererState() {
+        if (!ctx_) return;
+        for (auto& kv : meshes_) tr_mesh_destroy(ctx_, kv.second);
+        for (auto& kv : textures_) tr_texture_destroy(ctx_, kv.second);
+        tr_destroy(ctx_);
+    }
+    ModelRendererState(const ModelRendererState&) = delete;
+    ModelRendererState& operator=(const ModelRendererState&) = delete;
+
+    size_t frame_width() const { return w_; }
+    size_t frame_height() const { return h_; }
+    tr_context* context() { return ctx_; }
+
+    // state.z_buffer.nd_img: (W, H, 1) f64, -inf where nothing was drawn
+    std::vector<double> z_buffer() {
+        std::vector<double> v(w_ * h_);
+        check(tr_read_z_f64(ctx_, v.data(), TR_LAYOUT_REFERENCE), "tr_read_z_f64");
+        return v;
+    }
+    // state.frame_buffer.nd_img: (W, H, 4) f64
+    std::vector<double> frame_buffer() {
+        std::vector<double> v(w_ * h_ * 4);
+        check(tr_read_rgba_f64(ctx_, v.data(), TR_LAYOUT_REFERENCE), "tr_read_rgba_f64");
+        return v;
+    }
+    // ndarray_to_image_rgba_and_flip(&frame_buffer) (helpers/mod.rs:204-222): RGBA8 rows, row 0 = top
+    RgbaImage present() {
+        RgbaImage img;
+        img.width = (int)w_; img.height = (int)h_;
+        img.data.resize(w_ * h_ * 4);
+        check(tr_read_rgba8(ctx_, img.data.data(), 1), "tr_read_rgba8");
+        return img;
+    }
+    // shade without reading back (the frame loop's end of frame when nothing is displayed)
+    void resolve() { check(tr_resolve(ctx_, TR_OUT_RGBA8), "tr_resolve"); }
+    void synchronize() { check(tr_synchronize(ctx_), "tr_synchronize"); }
+
+    void check(int rc, const char* what) const {
+        if (rc != TR_OK) throw RendererError(std::string(what) + ": " + tr_last_error(ctx_));
+    }
+    // device copies are made once per mesh / image object (keyed by address: keep them alive)
+    tr_mesh* mesh_handle(const Object& o) {
+        auto it = meshes_.find(&o);
+        if (it != meshes_.end()) return it->second;
+        tr_mesh* h = nullptr;
+        check(tr_mesh_create(ctx_, o.vertices.data(), (int64_t)(o.vertices.size() / 3), o.normals.empty() ? nullptr : o.normals.data(),
+                             (int64_t)(o.normals.size() / 3), o.tex_vertices.empty() ? nullptr : o.tex_vertices.data(),
+                             (int64_t)(o.tex_vertices.size() / 3), o.triangles.empty() ? nullptr : o.triangles.data(),
+                             (int64_t)o.n_triangles(), &h),
+              "tr_mesh_create");
+        meshes_[&o] = h;
+        return h;
+    }
+    tr_texture* texture_handle(const RgbaImage& img) {
+        if (img.data.empty()) return nullptr;
+        auto it = textures_.find(&img);
+        if (it != textures_.end()) return it->second;
+        tr_texture* h = nullptr;
+        check(tr_texture_create(ctx_, img.data.data(), img.width, img.height, &h), "tr_texture_create");
+        textures_[&img] = h;
+        return h;
+    }
+
+  private:
+    tr_context* ctx_ = nullptr;
+    size_t w_, h_;
+    std::map<const Object*, tr_mesh*> meshes_;
+    std::map<const RgbaImage*, tr_texture*> textures_;
+};
+
+// src/model_renderer/mod.rs:210-219
+inline void clear_screen(ModelRendererState& state) { state.check(tr_clear(state.context()), "tr_clear"); }
+
+// render_mesh_component(state, &mesh, VS, FS) (mod.rs:225-230) with the closure pair replaced by
+// `shader`; takes the MeshComponent so the textures the closures capture (main.rs:140-141) come along.
+inline void render_mesh_component(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader) {
+    tr_draw_params p{};
+    const Matrix4 pmv = shader.perspective_matrix * shader.model_view_matrix;  // main.rs:152-153
+    for (int i = 0; i < 16; ++i) {
+        p.pmv[i] = pmv.m[i];
+        p.normal_mat[i] = shader.inverse_model_view_matrix.m[i];
+    }
+    p.light_dir[0] = shader.camera_pos.x; p.light_dir[1] = shader.camera_pos.y; p.light_dir[2] = shader.camera_pos.z;
+    p.ambient = shader.ambient_light;
+    p.intensity = shader.light_intensity;
+    for (int i = 0; i < 4; ++i) p.vertex_color[i] = shader.vertex_color[i];
+    p.use_normal_map = shader.use_normal_map ? 1 : 0;
+    p.diffuse = state.texture_handle(mesh_component.texture);
+    p.normal_map = state.texture_handle(mesh_component.normal_map);
+    state.check(tr_draw(state.context(), state.mesh_handle(mesh_component.mesh), &p), "tr_draw");
+}
+
+}  // namespace tinyrenderer

@@ -868,8 +868,10 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         // at the background colour too there is nothing to do; otherwise repaint the background.
         // (A NaN-depth winner is written outside the winner pass: no skipping in such a frame.)
         const bool touched = a.blk_touched[blk] != 0 || (a.nan && a.nan->pix[0] != kNanEmpty);
+        const bool painted = a.blk_painted[blk] != 0;
+        __syncthreads();  // every wave has read the flags before thread 0 rewrites them
         if (!touched) {
-            if (a.blk_painted[blk] == 0) return;
+            if (!painted) return;
             if (live) a.rgba8[pix] = 0xFF000000u;  // BLACK, helpers/mod.rs:22
             if (threadIdx.x == 0) a.blk_painted[blk] = 0;
             return;
