@@ -13,7 +13,11 @@
 //  and no Rust toolchain exists in the build container,
 // so the Rust binary cannot be run.  This oracle is pinned by (a) the
 // known-answer tests derived by hand from the cited source lines
-// (tests/test_oracle_kat.py) and (b) code review against the citations.
+// (tests/test_oracle_kat.py), (b) the one output artefact the reference holds,
+// sample.jpg (README.md:5, lossy, parameters unrecorded): the oracle's frame
+// correlates with it at 0.997 (tests/test_reference_sample.py), which pins
+// projection, z order, texture orientation, normal mapping and lighting but no
+// bits, and (c) code review against the citations.
 // Arithmetic that lives inside third-party crates whose source is not in the
 // container (nalgebra 0.30.1 gemv/dot/normalize/try_inverse association) is
 // restated from the crates' published algorithms and is "parity unpinned";
