@@ -87,4 +87,5 @@ def test_cpp_frame_loop_renders_the_reference_frame(oracle, tmp_path):
     draws = [(head, scenes.shader_for(head, W, Hh)), (eye, scenes.shader_for(eye, W, Hh))]
     want = SU.oracle_render(oracle, W, Hh, draws)["present"]
     diff = np.argwhere((got != want).any(axis=2))
+    eye.parent = None
     assert diff.shape[0] == 0, f"{diff.shape[0]} pixels differ, first {diff[:5].tolist()}, got {got[tuple(diff[0])]}, want {want[tuple(diff[0])]}"

@@ -51,3 +51,4 @@ def test_oracle_frame_matches_reference_screenshot(oracle):
     turned = [(head, scenes.shader_for(head, W, H)), (eye, scenes.shader_for(eye, W, H))]
     assert _ncc(_gray(SU.oracle_render(oracle, W, H, turned)["present"]), ref) < 0.9
     head.transform.set_rotation((0.025, 0.0, 0.0))
+    eye.parent = None

@@ -46,6 +46,7 @@ def _render_view(k, n_views, W, H):
     from tinyrenderer_amd import scenes
 
     mc = SU.component("eye_inner")
+    mc.parent = None  # (the component cache is shared with other tests of the session)
     draws = [(mc, scenes.shader_for(mc, W, H, eye=scenes.orbit_eye(k, n_views, radius=0.6)))]
     o = SU.oracle_render(oracle_ffi, W, H, draws)
     return np.ascontiguousarray(o["present"]).view(np.int32)[..., 0]  # (H, W) packed RGBA8
