@@ -2,7 +2,7 @@
 // the window: same scene (african_head + its inner eyes parented to it), same camera, same
 // per-frame rotation 0.025 * time, same "Frametime (nosync)" print.
 //
-//   frame_loop <asset_dir> [frames=100] [width=853] [height=480] [out.rgba]
+//   frame_loop <asset_dir> [frames=100] [width=853] [height=480] [out.rgba | out.png]
 //
 // With out.rgba the last frame is written as raw RGBA8 rows (row 0 = top), which is what
 // tests/test_host_cpp.py compares with the oracle.
@@ -69,7 +69,10 @@ int main(int argc, char** argv) {
         std::printf("%d frames of %zux%zu: mean %.3f ms\n", frames, frame_width, frame_height, total_us / frames / 1000.0);
         if (out_path) {
             const RgbaImage img = model_renderer_state.present();
-            if (FILE* f = std::fopen(out_path, "wb")) {
+            const std::string op = out_path;
+            if (op.size() > 4 && op.compare(op.size() - 4, 4, ".png") == 0) {
+                write_rgba_img_to_file(op, img);
+            } else if (FILE* f = std::fopen(out_path, "wb")) {
                 std::fwrite(img.data.data(), 1, img.data.size(), f);
                 std::fclose(f);
             } else {

@@ -218,6 +218,22 @@ inline RgbaImage flip_vertically(const RgbaImage& img) {
     return o;
 }
 
+// _write_nd_rgba_img_to_file (src/helpers/mod.rs:114-120): PNG of an RGBA8 image, row 0 = top
+inline void write_rgba_img_to_file(const std::string& path, const RgbaImage& img) {
+    if (tr_image_write_png(path.c_str(), img.data.data(), img.width, img.height) != TR_OK)
+        throw LoadError("write_rgba_img_to_file(" + path + "): " + tr_load_error());
+}
+
+// src/helpers/mod.rs:336-350: 1 / max(z, 0) where that is positive, else 0
+inline std::vector<double> get_drawable_z_buffer(const std::vector<double>& z_buffer) {
+    std::vector<double> out(z_buffer.size(), 0.0);
+    for (size_t i = 0; i < z_buffer.size(); ++i) {
+        const double val = std::fmax(z_buffer[i], 0.0);
+        if (val > 0.0) out[i] = 1.0 / val;
+    }
+    return out;
+}
+
 // The one-triangle mesh of src/helpers/mod.rs:558-608 (UVs, no normals)
 inline Object get_rando_mesh_object() {
     Object o;

@@ -194,6 +194,9 @@ int tr_image_load_rgba8(const char* path, int flip_vertically, tr_image** out);
 int tr_image_size(const tr_image* img, int* width, int* height);
 const uint8_t* tr_image_data(const tr_image* img);
 void tr_image_free(tr_image* img);
+/* helpers::_write_nd_rgba_img_to_file (src/helpers/mod.rs:114-120): 8-bit RGBA PNG of rgba8[height][width][4],
+ * row 0 = top (what tr_read_rgba8(.., flip = 1) returns). */
+int tr_image_write_png(const char* path, const uint8_t* rgba8, int width, int height);
 const char* tr_load_error(void);
 
 /* Library identity: returns a static string with the build's target arch and ABI version. */

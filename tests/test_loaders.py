@@ -189,3 +189,23 @@ def test_image_errors_are_reported(tmp_path):
     open(q, "wb").write(_tga(4, 4, 24, np.zeros((16, 3), np.uint8))[:30])
     with pytest.raises(_ffi.TrError):
         H.load_rgba_img_from_file(q)
+
+
+def test_png_writer_round_trips(tmp_path):
+    """helpers::_write_nd_rgba_img_to_file (src/helpers/mod.rs:114-120) through tr_image_write_png."""
+    rng = np.random.default_rng(5)
+    for w, h in ((1, 1), (7, 5), (301, 47)):
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        p = str(tmp_path / f"w_{w}x{h}.png")
+        H.write_rgba_img_to_file(p, img)
+        assert np.array_equal(np.asarray(PIL.open(p).convert("RGBA")), img)
+        assert PIL.open(p).mode == "RGBA"
+        assert np.array_equal(H.load_rgba_img_from_file(p), img)
+    with pytest.raises(_ffi.TrError):
+        H.write_rgba_img_to_file(str(tmp_path / "no_such_dir" / "x.png"), np.zeros((2, 2, 4), np.uint8))
+
+
+def test_drawable_z_buffer():
+    """helpers::get_drawable_z_buffer (src/helpers/mod.rs:336-350)."""
+    z = np.array([[-np.inf, -1.0, 0.0], [0.5, 4.0, np.nan]])
+    assert np.array_equal(H.get_drawable_z_buffer(z), np.array([[0.0, 0.0, 0.0], [2.0, 0.25, 0.0]]))

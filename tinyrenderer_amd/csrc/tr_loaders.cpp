@@ -376,4 +376,44 @@ int tr_image_size(const tr_image* img, int* width, int* height) {
 const uint8_t* tr_image_data(const tr_image* img) { return img ? img->rgba.data() : nullptr; }
 void tr_image_free(tr_image* img) { delete img; }
 
+// helpers::_write_nd_rgba_img_to_file (src/helpers/mod.rs:114-120): 8-bit RGBA PNG, rows as given
+// (row 0 = top), filter 0 on every row, one zlib stream in one IDAT.
+int tr_image_write_png(const char* path, const uint8_t* rgba8, int width, int height) {
+    if (!path || !rgba8 || width < 1 || height < 1) return TR_ERR_INVALID;
+    const size_t row = (size_t)width * 4;
+    std::vector<uint8_t> raw((row + 1) * (size_t)height);
+    for (int y = 0; y < height; ++y) {
+        raw[(row + 1) * y] = 0;
+        std::memcpy(&raw[(row + 1) * y + 1], rgba8 + row * y, row);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return load_fail(TR_ERR_HIP, "zlib compress failed");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return load_fail(TR_ERR_INVALID, std::string("cannot write ") + path + ": " + std::strerror(errno));
+    auto put32 = [](uint8_t* p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+    bool ok = true;
+    auto chunk = [&](const char* type, const uint8_t* data, size_t len) {
+        uint8_t hdr[8];
+        put32(hdr, (uint32_t)len);
+        std::memcpy(hdr + 4, type, 4);
+        uLong crc = crc32(0L, hdr + 4, 4);
+        if (len) crc = crc32(crc, data, (uInt)len);
+        uint8_t tail[4];
+        put32(tail, (uint32_t)crc);
+        ok = ok && std::fwrite(hdr, 1, 8, f) == 8 && (len == 0 || std::fwrite(data, 1, len, f) == len) && std::fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    ok = std::fwrite(sig, 1, 8, f) == 8;
+    uint8_t ihdr[13];
+    put32(ihdr, (uint32_t)width);
+    put32(ihdr + 4, (uint32_t)height);
+    ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8-bit RGBA, no interlace
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), (size_t)zlen);
+    chunk("IEND", nullptr, 0);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? TR_OK : load_fail(TR_ERR_INVALID, std::string("short write to ") + path);
+}
+
 }  // extern "C"

@@ -299,6 +299,27 @@ def load_rgba_img_from_file(path, flip=False):
         lib.tr_image_free(h)
 
 
+def write_rgba_img_to_file(path, img):
+    """`_write_nd_rgba_img_to_file` (src/helpers/mod.rs:114-120) for an (H, W, 4) uint8 image, row 0 = top."""
+    ffi, lib = _native()
+    img8 = np.ascontiguousarray(img, dtype=np.uint8)
+    if img8.ndim != 3 or img8.shape[2] != 4:
+        raise ValueError("image must be (H, W, 4) uint8")
+    rc = lib.tr_image_write_png(os.fsencode(path), img8.ctypes.data, img8.shape[1], img8.shape[0])
+    if rc != ffi.TR_OK:
+        raise ffi.TrError(f"tr_image_write_png({path}): {ffi.TR_ERR.get(rc, rc)} {lib.tr_load_error().decode(errors='replace')}")
+
+
+def get_drawable_z_buffer(z_buffer):
+    """src/helpers/mod.rs:336-350: 1 / max(z, 0) where that is positive, else 0 (same shape)."""
+    z = np.asarray(z_buffer, dtype=np.float64)
+    val = np.fmax(z, 0.0)  # f64::max: NaN -> 0
+    out = np.zeros_like(val)
+    pos = val > 0.0
+    out[pos] = 1.0 / val[pos]
+    return out
+
+
 def flip_vertically(img):
     """src/helpers/mod.rs:291-302 on an (H, W, C) image: row y <- row H-1-y."""
     return np.ascontiguousarray(img[::-1])
