@@ -102,6 +102,8 @@ struct tr_context {
     bool precheck = true;          // plain-load filter in front of the depth atomics
     bool precheck_winner = false;  // ... and in front of the winner atomics
     bool skip_dead = true;         // winner pass skips chunks the depth pass found dead
+    bool fused_front = true;       // small draws: transform + setup + scan in one launch (TR_FUSED_FRONT)
+    uint32_t* ticket = nullptr;
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double prof_ms[ST_COUNT] = {0};
@@ -418,6 +420,7 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (const char* e = std::getenv("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SCAN_RECORDS")) c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_ROW_REFS")) c->ref_cap = (uint32_t)std::strtoul(e, nullptr, 10);
     if (c->ref_cap < 1) c->ref_cap = 1;
@@ -457,6 +460,8 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     }
     if (hipMalloc(&c->nan, sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->ticket, 64) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMemsetAsync(c->ticket, 0, 64, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     {
         c->nseg = (width + kSegW - 1) / kSegW;
         const size_t n_bins = (size_t)c->nseg * height;
@@ -493,7 +498,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->state_blk); (void)hipFree(c->nan);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -647,7 +652,9 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
     Mat4 pmv, nmat;
     std::memcpy(pmv.m, p->pmv, sizeof(pmv.m));
     std::memcpy(nmat.m, p->normal_mat, sizeof(nmat.m));
-    {
+    // small draws (the reference's meshes): one launch does vertex stage + setup + prefix
+    const bool fused = c->fused_front && c->mode != 1 && 2u * (uint64_t)mesh->n_tris <= 8u * (uint64_t)kScanTile;
+    if (!fused) {
         ProfScope ps(c, ST_TRANSFORM);
         int n = (int)(mesh->n_pos + mesh->n_nrm);
         hipLaunchKernelGGL(k_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, mesh->pos, (int)mesh->n_pos,
@@ -689,9 +696,12 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
         for (int i = 0; i < 4; ++i) d.vcol[i] = p->vertex_color[i];
         d.use_nm = p->use_normal_map && p->normal_map;
         sa.draw_table = c->draw_table;
-        hipLaunchKernelGGL(k_setup, dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
+        sa.nrm = mesh->nrm; sa.pmv = pmv; sa.ticket = c->ticket; sa.half_off = c->half_off;
+        sa.scan_lo = 2u * tri_base; sa.n_halves = n_halves;
+        if (fused) hipLaunchKernelGGL((k_setup<true>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
+        else hipLaunchKernelGGL((k_setup<false>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
-        if (c->mode != 1) {
+        if (c->mode != 1 && !fused) {
             // prefix of scanline counts, continuing from the previous draw's total
             const uint32_t lo = 2u * tri_base;
             uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;

@@ -59,12 +59,52 @@ struct SetupArgs {
     uint32_t* flags;
     DrawDev params;
     DrawDev* draw_table;
+    // fused front end (small draws): the vertex stage is evaluated per triangle corner instead of
+    // read back, and the workgroup that finishes last scans the draw's slot counts
+    const double* nrm;     // raw normals
+    Mat4 pmv;              // perspective * model_view
+    uint32_t* ticket;      // arrival counter of the draw's workgroups (zero between launches)
+    uint32_t* half_off;    // prefix to write: half_off[scan_lo + 1 .. scan_lo + n_halves]
+    uint32_t scan_lo, n_halves;
 };
 
+__device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
+                                              uint32_t* flags);
+
+__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused);
+
+// FUSED = false: vertex stage read from k_transform's arrays, prefix by the k_scan_* kernels.
+// FUSED = true (draws of up to 8 scan tiles): one launch does transform + setup + scan.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) a.draw_table[a.draw] = a.params;
-    if (k >= a.n_tris) return;
+    if (k < a.n_tris) setup_triangle(a, k, FUSED);
+    if (!FUSED) return;
+    // ---- the last workgroup to arrive scans half_cnt of this draw.  Publication follows
+    // cdna_hip_programming.md ("in-launch split-K reduction"): every wave drains its stores, one
+    // agent-scope release before the ticket, one agent-scope acquire in the last arriver.
+    __shared__ uint32_t s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next draw
+    }
+    __syncthreads();
+    scan_in_block(a.half_cnt + a.scan_lo, a.n_halves, a.half_off + a.scan_lo, a.flags);
+}
+
+__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused) {
     const uint32_t* ix = a.idx + 9 * (size_t)k;
     uint32_t iv[3] = {ix[0], ix[3], ix[6]};
     uint32_t it[3] = {ix[1], ix[4], ix[7]};
@@ -75,9 +115,17 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     double px[3], py[3], pz[3];  // clip_space_position (after divide), main.rs:154-162
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        px[c] = a.ndc[iv[c]];
-        py[c] = a.ndc[a.n_pos + iv[c]];
-        pz[c] = a.ndc[2 * a.n_pos + iv[c]];
+        if (fused) {  // k_transform's arithmetic, per corner
+            double g[4];
+            mat4_mul_vec4(a.pmv, a.pos[3 * (size_t)iv[c]], a.pos[3 * (size_t)iv[c] + 1], a.pos[3 * (size_t)iv[c] + 2], 1.0, g);
+            px[c] = g[0] / g[3];
+            py[c] = g[1] / g[3];
+            pz[c] = g[2] / g[3];
+        } else {
+            px[c] = a.ndc[iv[c]];
+            py[c] = a.ndc[a.n_pos + iv[c]];
+            pz[c] = a.ndc[2 * a.n_pos + iv[c]];
+        }
     }
     // mod.rs:293-312: cull iff all three corners are outside on their own.
     bool cull = true;
@@ -185,7 +233,11 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (in[c] != 0xFFFFFFFFu) {
+            if (in[c] != 0xFFFFFFFFu && fused) {
+                double g[4];
+                mat4_mul_vec4(a.nmat, a.nrm[3 * (size_t)in[c]], a.nrm[3 * (size_t)in[c] + 1], a.nrm[3 * (size_t)in[c] + 2], 0.0, g);
+                S.n[c][0] = g[0]; S.n[c][1] = g[1]; S.n[c][2] = g[2];
+            } else if (in[c] != 0xFFFFFFFFu) {
                 S.n[c][0] = a.nout[in[c]];
                 S.n[c][1] = a.nout[a.n_nrm + in[c]];
                 S.n[c][2] = a.nout[2 * a.n_nrm + in[c]];
@@ -401,8 +453,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __r
 }
 
 // single block: the whole scan for up to a few tiles (one launch instead of three)
-__global__ __launch_bounds__(kScanThreads) void k_scan_small(const uint32_t* __restrict__ cnt, uint32_t n,
-                                                             uint32_t* off, uint32_t* flags) {
+__device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
+                                              uint32_t* flags) {
     __shared__ unsigned long long carry;
     if (threadIdx.x == 0) carry = off[0];
     __syncthreads();
@@ -431,6 +483,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_small(const uint32_t* __r
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_small(const uint32_t* __restrict__ cnt, uint32_t n,
+                                                             uint32_t* off, uint32_t* flags) {
+    scan_in_block(cnt, n, off, flags);
 }
 
 // =============================================================== (3) raster
@@ -784,6 +841,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     }
 }
 
+template __global__ void k_setup<false>(SetupArgs);
+template __global__ void k_setup<true>(SetupArgs);
 template __global__ void k_raster<0, true>(RasterArgs);
 template __global__ void k_raster<1, true>(RasterArgs);
 template __global__ void k_raster<0, false>(RasterArgs);
