@@ -57,6 +57,7 @@ struct tr_context {
     uint32_t* half_off = nullptr;
     ScanRec* rec = nullptr;          // scanline records of the frame's first rec_cap slots
     uint32_t rec_cap = 1u << 20;     // 64 MB; slots beyond are rebuilt by every raster pass (TR_SCAN_RECORDS)
+    bool rec_auto = true;            // grow with the first draw of a frame unless TR_SCAN_RECORDS pins the size
     uint8_t* chunk_live = nullptr;
     // row raster (mode 2)
     uint32_t* bin_cnt = nullptr;
@@ -103,6 +104,7 @@ struct tr_context {
     bool precheck_winner = false;  // ... and in front of the winner atomics
     bool skip_dead = true;         // winner pass skips chunks the depth pass found dead
     bool fused_front = true;       // small draws: transform + setup + scan in one launch (TR_FUSED_FRONT)
+    uint32_t big_draw_tris = 65536;  // draws at least this large get their records from k_scanlines (TR_BIG_DRAW)
     uint32_t* ticket = nullptr;
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -205,6 +207,7 @@ int ensure_scratch(tr_context* c, double** p, size_t* cap, size_t need) {
 
 constexpr int kRasterBlocks = 4096;
 constexpr int kRowBinBlocks = 1024;
+constexpr int kScanlineBlocks = 2048;
 constexpr int kRowGrid = 256 * 15;  // waves: 15 per CU fit the LDS (10.3 KB each)
 constexpr uint32_t kChunkLiveCap = 1u << 20;  // 64 M slots per frame get dead-chunk skipping
 
@@ -230,16 +233,18 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.chunk_live = c->chunk_live;
     ra.live_cap = kChunkLiveCap;
     ra.use_live = 0;
+    ra.rec_ready = 0;
     ra.debug = 0;
     ra.trace = nullptr;
     ra.trace_cap = 0;
 }
 
 // passes 0 / 1 over the half range [h_lo, h_hi)
-int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool use_live = false) {
+int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool use_live = false, bool rec_ready = false) {
     RasterArgs ra;
     fill_raster_args(c, ra, h_lo, h_hi);
     ra.use_live = use_live && c->skip_dead ? 1 : 0;
+    ra.rec_ready = rec_ready ? 1 : 0;
     if (const char* e = std::getenv("TR_RASTER_DEBUG")) ra.debug = std::atoi(e);
     static const char* trace_path = std::getenv("TR_RASTER_TRACE");  // debugging aid, see tools/raster_trace.py
     static unsigned long long* trace_buf = nullptr;
@@ -421,7 +426,11 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_SCAN_RECORDS")) c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TR_SCAN_RECORDS")) {
+        c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
+        c->rec_auto = false;
+    }
     if (const char* e = std::getenv("TR_ROW_REFS")) c->ref_cap = (uint32_t)std::strtoul(e, nullptr, 10);
     if (c->ref_cap < 1) c->ref_cap = 1;
     auto bail = [&](int code) {
@@ -644,6 +653,18 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
     }
     int rc = ensure_tri_capacity(c, (size_t)c->tri_total + (size_t)mesh->n_tris);
     if (rc != TR_OK) return rc;
+    if (c->tri_total == 0 && c->rec_auto && c->mode != 1) {
+        // a triangle of a few pixels takes 6-8 slots; records beyond the buffer cost a rebuild per pass
+        uint64_t want = 8ull * (uint64_t)mesh->n_tris;
+        if (want > (64ull << 20)) want = 64ull << 20;  // 4 GB of records at most
+        if (want > c->rec_cap) {
+            TR_HIP(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->rec);
+            c->rec = nullptr;
+            TR_HIP(c, hipMalloc(&c->rec, want * sizeof(ScanRec)));
+            c->rec_cap = (uint32_t)want;
+        }
+    }
     rc = ensure_scratch(c, &c->ndc, &c->ndc_cap, (size_t)mesh->n_pos * 3);
     if (rc != TR_OK) return rc;
     rc = ensure_scratch(c, &c->nout, &c->nout_cap, (size_t)(mesh->n_nrm ? mesh->n_nrm : 1) * 3);
@@ -724,7 +745,15 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
         // depth plane is current up to this draw: add this draw's samples now.  (If an earlier
         // resolve wiped the planes, the depth pass of the whole frame is redone at tr_resolve.)
         ProfScope ps(c, ST_DEPTH);
-        rc = launch_raster(c, 0, 2u * tri_base, 2u * tri_base + n_halves);
+        // many small triangles: build the records with one thread per slot first
+        const bool big = (uint64_t)mesh->n_tris >= (uint64_t)c->big_draw_tris;
+        if (big) {
+            RasterArgs ra;
+            fill_raster_args(c, ra, 2u * tri_base, 2u * tri_base + n_halves);
+            hipLaunchKernelGGL(k_scanlines, dim3(kScanlineBlocks), dim3(256), 0, c->stream, ra);
+            TR_HIP(c, hipGetLastError());
+        }
+        rc = launch_raster(c, 0, 2u * tri_base, 2u * tri_base + n_halves, false, big);
         if (rc != TR_OK) return rc;
         c->depth_upto = tri_base + (uint32_t)mesh->n_tris;
         c->planes_clean = false;

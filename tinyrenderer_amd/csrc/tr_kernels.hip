@@ -514,6 +514,7 @@ struct RasterArgs {
     uint8_t* chunk_live;        // per 64-slot chunk of the frame: 1 = some sample may be a winner
     uint32_t live_cap;          // chunks beyond this are always treated as live
     int use_live;               // winner pass: skip chunks the depth pass found dead
+    int rec_ready;              // depth pass: k_scanlines already built this range's records
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
     unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
                                 // ticks, samples | block << 32)
@@ -577,6 +578,58 @@ __device__ __forceinline__ ScanRec build_record(const RasterArgs& a, uint32_t g)
 
 constexpr int kHalfCache = 256;  // prefix entries a chunk can hold in LDS while it locates its halves
 
+// Large draws of small triangles (BASELINE.json configs[3]): one thread per slot builds the
+// records ahead of the depth pass, which would otherwise build them 64 at a time with one wave
+// per workgroup.  A block owns 256 consecutive slots; two waves locate the halves of its first and
+// last slot, the prefix entries between them go to LDS, each thread finishes its search there.
+constexpr int kScanlineCache = 1024;
+__global__ __launch_bounds__(256) void k_scanlines(RasterArgs a) {
+    __shared__ uint32_t sOff[kScanlineCache + 1];
+    __shared__ uint32_t sEnds[2];
+    const uint32_t s_begin = a.half_off[a.h_lo];
+    const uint32_t s_end = a.half_off[a.h_hi];
+    unsigned long long n_scan = 0;
+    for (unsigned long long b0 = (unsigned long long)s_begin + (unsigned long long)blockIdx.x * 256ull; b0 < s_end;
+         b0 += (unsigned long long)gridDim.x * 256ull) {
+        const uint32_t g_first = (uint32_t)b0;
+        const uint32_t g_last = (uint32_t)(b0 + 255ull < s_end ? b0 + 255ull : (unsigned long long)s_end - 1ull);
+        const int w = threadIdx.x >> 6;
+        if (w < 2) {
+            const uint32_t e = find_half_wave(a.half_off, a.h_lo, a.h_hi, w == 0 ? g_first : g_last);
+            if ((threadIdx.x & 63) == 0) sEnds[w] = e;
+        }
+        __syncthreads();
+        const uint32_t e_first = sEnds[0], e_last = sEnds[1];
+        const uint32_t n_e = e_last - e_first + 1u;
+        const bool cached = n_e <= (uint32_t)kScanlineCache;
+        if (cached)
+            for (uint32_t t = threadIdx.x; t <= n_e; t += 256u) sOff[t] = a.half_off[e_first + t];
+        __syncthreads();
+        const uint32_t g = g_first + threadIdx.x;
+        if (g <= g_last) {
+            uint32_t lo;
+            if (cached) {
+                uint32_t l = 0, h = n_e;  // sOff[l] <= g < sOff[h]
+                while (h - l > 1u) {
+                    uint32_t mid = (l + h) >> 1;
+                    if (sOff[mid] <= g) l = mid; else h = mid;
+                }
+                lo = e_first + l;
+            } else {
+                lo = find_half(a.half_off, e_first, e_last + 1u, g);
+            }
+            const ScanRec r = record_of(a, lo, g);
+            if (g < a.rec_cap) a.rec[g] = r;  // slots beyond the capacity are rebuilt by every raster pass
+            n_scan += (lo >= a.count_h && (r.keyh & kRecHresMask)) ? 1 : 0;
+        }
+        __syncthreads();  // sOff / sEnds are rewritten by the next round
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_scan += __shfl_down(n_scan, d, 64);
+    if ((threadIdx.x & 63) == 0 && n_scan)
+        atomicAdd(&a.counters[(size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8 + 2], n_scan);
+}
+
 constexpr int kRasterThreads = 256;
 constexpr int kChunkSlots = 64;
 
@@ -623,7 +676,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         // of its first and last slot with 64 probes per round, the prefix entries between them go
         // to LDS, 64 lanes finish their search there), keep them in LDS and store them for the
         // winner pass.  Winner pass: thread t brings 16 bytes (part t & 3) of slot t >> 2.
-        if (PASS == 0) {
+        if (PASS == 0 && !a.rec_ready) {
             const uint32_t g_first = chunk * 64u > s_begin ? chunk * 64u : s_begin;
             const uint32_t g_last = chunk * 64u + 63u < s_end - 1u ? chunk * 64u + 63u : s_end - 1u;
             if (g_first > g_last) continue;  // (uniform) the range ends exactly at this chunk's start
