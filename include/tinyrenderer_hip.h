@@ -199,6 +199,12 @@ void tr_image_free(tr_image* img);
 int tr_image_write_png(const char* path, const uint8_t* rgba8, int width, int height);
 const char* tr_load_error(void);
 
+/* Device self-test of the exact arithmetic shortcuts the kernels use (no counterpart in the reference):
+ * runs them against the operations they stand for on about n_values pseudo-random operands.
+ * out[0] reserved (0), out[1] x/255 as multiply + fmas vs `/`, out[2] pixel
+ * rounding vs round(): numbers of mismatches (all must be 0); out[3] operands tried per check. */
+int tr_selftest_arithmetic(int device, uint64_t n_values, uint64_t seed, uint64_t out[4]);
+
 /* Library identity: returns a static string with the build's target arch and ABI version. */
 const char* tr_version(void);
 

@@ -454,3 +454,19 @@ def test_row_raster_grows_its_buffers(oracle, monkeypatch):
             assert g["counters"][k] == o["counters"][k], (env, k)
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_device_arithmetic_shortcuts_are_exact():
+    """tr_selftest_arithmetic: x/255 by fmas and the rounding shortcut against `/` and round() on
+    the device, 6e8 operands each."""
+    import ctypes as C
+
+    from tinyrenderer_amd import _ffi
+
+    lib = _ffi.load()
+    out = (C.c_uint64 * 4)()
+    for seed in (1, 0xC0FFEE):
+        rc = lib.tr_selftest_arithmetic(0, 300_000_000, seed, out)
+        assert rc == 0
+        assert out[3] >= 200_000_000
+        assert list(out[:3]) == [0, 0, 0], list(out)

@@ -14,3 +14,11 @@ def test_round_trick_matches_round(tmp_path):
                    check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
     assert " 0 mismatches" in out, out
+
+
+def test_div255_matches_division(tmp_path):
+    """tr_device.h div255 (x / 255.0 as a multiply and two fmas) against the division on 3e8 values."""
+    exe = str(tmp_path / "div255")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(HERE, "ctools", "div255.c"), "-lm"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout
+    assert " 0 mismatches" in out, out

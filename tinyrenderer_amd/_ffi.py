@@ -40,7 +40,7 @@ EXPORTS = [
     "tr_device_ptr_rgba8", "tr_profile_enable", "tr_profile_read", "tr_version", "tr_set_band",
     "tr_set_raster_mode", "tr_obj_load", "tr_obj_parse", "tr_obj_counts", "tr_obj_positions", "tr_obj_uvw",
     "tr_obj_normals", "tr_obj_indices", "tr_obj_free", "tr_image_load_rgba8", "tr_image_size", "tr_image_data",
-    "tr_image_free", "tr_load_error", "tr_image_write_png",
+    "tr_image_free", "tr_load_error", "tr_image_write_png", "tr_selftest_arithmetic",
 ]
 
 
@@ -115,6 +115,7 @@ def load():
         "tr_image_free": (None, [vp]),
         "tr_load_error": (C.c_char_p, []),
         "tr_image_write_png": (i32, [C.c_char_p, vp, i32, i32]),
+        "tr_selftest_arithmetic": (i32, [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

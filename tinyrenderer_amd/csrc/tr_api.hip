@@ -1036,6 +1036,30 @@ int tr_set_raster_mode(tr_context* c, int mode) {
     return TR_OK;
 }
 
+int tr_selftest_arithmetic(int device, uint64_t n_values, uint64_t seed, uint64_t out[4]) {
+    if (!out) return TR_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return TR_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TR_ERR_NO_DEVICE;
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, 4 * sizeof(unsigned long long)) != hipSuccess) return TR_ERR_OOM;
+    int rc = TR_OK;
+    const int blocks = 2048, threads = 256;
+    uint64_t per = n_values / ((uint64_t)blocks * threads);
+    if (per < 1) per = 1;
+    if (per > 0xFFFFFFFFull) per = 0xFFFFFFFFull;
+    if (hipMemset(d, 0, 4 * sizeof(unsigned long long)) != hipSuccess) rc = TR_ERR_HIP;
+    if (rc == TR_OK) {
+        hipLaunchKernelGGL(k_selftest, dim3(blocks), dim3(threads), 0, nullptr, (unsigned long long)(seed ? seed : 1), (uint32_t)per, d);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = TR_ERR_HIP;
+    }
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (rc == TR_OK && hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) rc = TR_ERR_HIP;
+    (void)hipFree(d);
+    for (int i = 0; i < 4; ++i) out[i] = h[i];
+    return rc;
+}
+
 int tr_profile_enable(tr_context* c, int enable) {
     if (!c) return TR_ERR_INVALID;
     c->prof = enable != 0;

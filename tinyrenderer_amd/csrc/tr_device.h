@@ -145,11 +145,10 @@ struct Scanline {
     double ax, ay, az, dx, dy, dz;  // A and B-A
     uint32_t hres;                  // horizontal resolution (>= 2), or kBig+1 if too long
 };
-__device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t half, uint32_t i) {
+__device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t half, uint32_t i, double delta) {
     const double* a1 = half ? r.s2 : r.s0;
     const double* a2 = r.s1;
     const double* b2 = r.sp;
-    double delta = 1.0 / (double)r.res[half];
     double t = (double)i * delta;
     double Ax = a1[0] + t * (a2[0] - a1[0]);
     double Ay = a1[1] + t * (a2[1] - a1[1]);
@@ -169,6 +168,9 @@ __device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t h
     s.hres = h < 2u ? 2u : h;
     return s;
 }
+__device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t half, uint32_t i) {
+    return make_scanline(r, half, i, 1.0 / (double)r.res[half]);
+}
 
 
 // One slot of the frame's scanline sequence as the raster passes consume it (global raster):
@@ -180,5 +182,22 @@ struct __attribute__((aligned(64))) ScanRec {
 };
 static_assert(sizeof(ScanRec) == 64, "ScanRec must be 64 B");
 constexpr unsigned long long kRecHresMask = 0x3FFFFull;
+
+
+// x / 255.0, correctly rounded, in 3 operations instead of the ~11 of a general f64 division.
+// With r = RN(1/255): q = RN(x r), e = x - 255 q (exact in an fma: a multiple of ulp(q) below
+// 2^9 ulp(q)), result = RN(q + e r) = RN(v + (v - q) eps) with v = x/255, |eps| <= 2^-53, i.e. v
+// perturbed by less than 2^-104 |v|.  v = X 2^k / 255 with X < 2^53 is never closer than
+// 2^-62 |v| to a rounding boundary (255 (2M+1) 2^(j-1) = X 2^k has an odd left and an even right
+// side), so the perturbation cannot change the rounding.  Outside the normal range, for zeros
+// (whose sign the fmas lose) and for non-finite x the plain division is used.  tests/test_round_trick.py checks it on the host.
+__device__ __forceinline__ double div255(double x) {
+    const double ax = fabs(x);
+    if (__builtin_expect(!(ax < 1e150) || ax < 1e-150, 0)) return x / 255.0;
+    constexpr double r = 1.0 / 255.0;
+    const double q = x * r;
+    const double e = __builtin_fma(-255.0, q, x);
+    return __builtin_fma(e, r, q);
+}
 
 }  // namespace tr

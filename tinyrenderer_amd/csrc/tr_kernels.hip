@@ -1024,13 +1024,13 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         uint32_t i = (uint32_t)(key >> kKeyIShift) & 0x1FFFFu;
         uint32_t j = (uint32_t)key & 0x3FFFFu;
         const TriRaster& r = a.rast[tri];
+        const TriShade& s = a.shade[tri];
         Scanline sl = make_scanline(r, half, i);
         double sp = (double)j * (1.0 / (double)sl.hres);
         double px = sl.ax + sp * sl.dx;
         double py = sl.ay + sp * sl.dy;
         double pz = sl.az + sp * sl.dz;
         zval = -pz;
-        const TriShade& s = a.shade[tri];
         const DrawDev& dp = a.draws[s.draw];
         // helpers/mod.rs:326-333 barycentrics w.r.t. the UNSORTED viewport triangle
         double det = ((s.uy[1] - s.uy[2]) * (s.ux[0] - s.ux[2])) + ((s.ux[2] - s.ux[1]) * (s.uy[0] - s.uy[2]));
@@ -1052,9 +1052,9 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         if (has_uv && has_tb && dp.use_nm) {
             double rgb[3];
             sample_rgb(dp.nm, dp.nw, dp.nh, u * (double)(dp.nw - 1), v * (double)(dp.nh - 1), rgb, a.flags);
-            double mx = ((rgb[0] / 255.0) * 2.0) - 1.0;
-            double my = ((rgb[1] / 255.0) * 2.0) - 1.0;
-            double mz = ((rgb[2] / 255.0) * 2.0) - 1.0;
+            double mx = (div255(rgb[0]) * 2.0) - 1.0;
+            double my = (div255(rgb[1]) * 2.0) - 1.0;
+            double mz = (div255(rgb[2]) * 2.0) - 1.0;
             double rx = (s.t[0] * mx + s.b[0] * my) + nx * mz;
             double ry = (s.t[1] * mx + s.b[1] * my) + ny * mz;
             double rz = (s.t[2] * mx + s.b[2] * my) + nz * mz;
@@ -1109,6 +1109,62 @@ __global__ __launch_bounds__(256) void k_clear_state(unsigned long long* state_b
             nan->first_any[t] = kKeyNone;
         }
     }
+}
+
+
+// ============================================================ arithmetic self-test
+// The exact shortcuts of tr_device.h against the operations they stand for, on the device:
+// [0] reserved (0), [1] div255 vs `/ 255.0`, [2] pixel_coord vs round(), [3] values tried per check.
+__device__ __forceinline__ unsigned long long st_next(unsigned long long& s) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    return s;
+}
+__device__ __forceinline__ double st_double(unsigned long long& s, int exp_span) {
+    // random sign and mantissa, exponent uniform in [-exp_span, exp_span]
+    unsigned long long b = st_next(s);
+    long long e = 1023 + (long long)(st_next(s) % (unsigned long long)(2 * exp_span + 1)) - exp_span;
+    b = (b & 0x800FFFFFFFFFFFFFull) | ((unsigned long long)e << 52);
+    return __longlong_as_double((long long)b);
+}
+__device__ __forceinline__ int pixel_coord_by_round(double v, int n) {
+    double r = round(v);
+    if (r != r) return 0;
+    if (r < 0.0 || r > (double)(n - 1)) return -1;
+    return (int)r;
+}
+__global__ __launch_bounds__(256) void k_selftest(unsigned long long seed, uint32_t per_thread, unsigned long long* out) {
+    unsigned long long s = seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x + 1));
+    unsigned long long bad0 = 0, bad1 = 0, bad2 = 0;
+    auto differ = [](double a, double b) {
+        return __double_as_longlong(a) != __double_as_longlong(b) && !(a != a && b != b);
+    };
+    for (uint32_t it = 0; it < per_thread; ++it) {
+        const int span = (it & 7) == 0 ? 600 : ((it & 7) == 1 ? 1022 : 40);  // mostly the shader's range, some extremes
+        const double den = st_double(s, span);
+        double num = st_double(s, span);
+        if ((it & 15) == 2) num = den * (double)(st_next(s) % 1000);  // exact quotients
+        if ((it & 15) == 3) num = 0.0;
+        if ((it & 31) == 4) num = __longlong_as_double(0x7FF0000000000000ll);
+        (void)den;
+        // bilinear mixes of bytes, plus arbitrary values
+        const double fx = (double)(st_next(s) >> 11) * 0x1p-53, fy = (double)(st_next(s) >> 11) * 0x1p-53;
+        const unsigned long long t = st_next(s);
+        const double mix = (double)(t & 255) * ((1.0 - fx) * (1.0 - fy)) + (double)((t >> 8) & 255) * (fx * (1.0 - fy)) +
+                           (double)((t >> 16) & 255) * ((1.0 - fx) * fy) + (double)((t >> 24) & 255) * (fx * fy);
+        bad1 += differ(div255(mix), mix / 255.0) ? 1 : 0;
+        bad1 += differ(div255(num), num / 255.0) ? 1 : 0;
+        // pixel coordinates: around half-integers and anywhere
+        const double base = (double)((long long)(st_next(s) % 8200) - 50) * 0.5;
+        const long long ulps = (long long)(st_next(s) % 9) - 4;
+        const double near = __longlong_as_double(__double_as_longlong(base) + (base != 0.0 ? ulps : 0));
+        bad2 += pixel_coord(near, 4096) != pixel_coord_by_round(near, 4096) ? 1 : 0;
+        bad2 += pixel_coord(num, 4096) != pixel_coord_by_round(num, 4096) ? 1 : 0;
+        bad2 += pixel_coord(fx * 4100.0 - 2.0, 4096) != pixel_coord_by_round(fx * 4100.0 - 2.0, 4096) ? 1 : 0;
+    }
+    if (bad0) atomicAdd(&out[0], bad0);
+    if (bad1) atomicAdd(&out[1], bad1);
+    if (bad2) atomicAdd(&out[2], bad2);
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[3] = (unsigned long long)per_thread * gridDim.x * blockDim.x;
 }
 
 }  // namespace tr
