@@ -79,6 +79,7 @@ struct tr_context {
     double* nout = nullptr;
     size_t ndc_cap = 0, nout_cap = 0;
     DrawDev* draw_table = nullptr;
+    DrawDev draw0;                   // host copy of the frame's first draw (a kernel argument of the shade pass)
     uint32_t draw_cap = 4096;
     unsigned long long* state_blk = nullptr;     // counters | cov_counters | flags, one allocation
     unsigned long long* counters = nullptr;      // kCounterSlots x 8: [0] samples [1] fragments
@@ -717,6 +718,7 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
         for (int i = 0; i < 4; ++i) d.vcol[i] = p->vertex_color[i];
         d.use_nm = p->use_normal_map && p->normal_map;
         sa.draw_table = c->draw_table;
+        if (c->draw_count == 0) c->draw0 = d;
         sa.nrm = mesh->nrm; sa.pmv = pmv; sa.ticket = c->ticket; sa.half_off = c->half_off;
         sa.scan_lo = 2u * tri_base; sa.n_halves = n_halves;
         if (fused) hipLaunchKernelGGL((k_setup<true>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
@@ -889,6 +891,7 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         sa.W = c->W; sa.H = c->H; sa.out_mask = out_mask; sa.rgba8 = c->rgba8; sa.z_out = c->z_out;
         sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.cov_counters = c->cov_counters;
         sa.blk_touched = c->blk_flags; sa.blk_painted = c->blk_flags + c->n_blk;
+        sa.draw0 = c->draw0;
         sa.skip_clean = (sa.self_clean && c->skip_clean) ? 1 : 0;
         if (c->cov_dirty)  // a second resolve of the same frame: tr_clear zeroes them otherwise
             TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));

@@ -924,6 +924,7 @@ struct ShadeArgs {
     uint8_t* blk_touched;  // per 32x8 block: the winner pass wrote a key into it this frame
     uint8_t* blk_painted;  // per block: rgba8 holds something other than the background
     int skip_clean;        // blocks neither touched nor painted are left alone (RGBA8-only resolve, global raster)
+    DrawDev draw0;         // copy of draws[0]
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -1031,7 +1032,8 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         double py = sl.ay + sp * sl.dy;
         double pz = sl.az + sp * sl.dz;
         zval = -pz;
-        const DrawDev& dp = a.draws[s.draw];
+        // the draw is the same for the whole wave almost always (always, in a one-draw frame): its
+        // constants then come through the scalar cache into SGPRs instead of 112 B per lane through L1
         // helpers/mod.rs:326-333 barycentrics w.r.t. the UNSORTED viewport triangle
         double det = ((s.uy[1] - s.uy[2]) * (s.ux[0] - s.ux[2])) + ((s.ux[2] - s.ux[1]) * (s.uy[0] - s.uy[2]));
         double l1 = (((s.uy[1] - s.uy[2]) * (px - s.ux[2])) + ((s.ux[2] - s.ux[1]) * (py - s.uy[2]))) / det;
@@ -1048,32 +1050,39 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             u = l1 * s.uv[0][0] + l2 * s.uv[1][0] + l3 * s.uv[2][0];
             v = l1 * s.uv[0][1] + l2 * s.uv[1][1] + l3 * s.uv[2][1];
         }
-        // main.rs:183-218
-        if (has_uv && has_tb && dp.use_nm) {
-            double rgb[3];
-            sample_rgb(dp.nm, dp.nw, dp.nh, u * (double)(dp.nw - 1), v * (double)(dp.nh - 1), rgb, a.flags);
-            double mx = (div255(rgb[0]) * 2.0) - 1.0;
-            double my = (div255(rgb[1]) * 2.0) - 1.0;
-            double mz = (div255(rgb[2]) * 2.0) - 1.0;
-            double rx = (s.t[0] * mx + s.b[0] * my) + nx * mz;
-            double ry = (s.t[1] * mx + s.b[1] * my) + ny * mz;
-            double rz = (s.t[2] * mx + s.b[2] * my) + nz * mz;
-            normalize3(rx, ry, rz);
-            nx = rx; ny = ry; nz = rz;
-        }
-        // main.rs:221-247
-        double albedo[3];
-        if (has_uv) {
-            sample_rgb(dp.tex, dp.tw, dp.th, u * (double)(dp.tw - 1), v * (double)(dp.th - 1), albedo, a.flags);
-        } else {  // mod.rs:518-525 colour interpolation
-#pragma unroll
-            for (int c = 0; c < 3; ++c) albedo[c] = l1 * dp.vcol[c] + l2 * dp.vcol[c] + l3 * dp.vcol[c];
-        }
-        // main.rs:248-265
-        double d = fmax(dot3(nx, ny, nz, dp.light[0], dp.light[1], dp.light[2]), 0.0);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) col[c] = fmin(dp.ambient + (d * dp.intensity * albedo[c]), 255.0);
-        col[3] = 255.0;
+        // Waves whose pixels all belong to the frame's first draw (all of them in a one-draw frame)
+        // take its constants from the kernel arguments, i.e. from SGPRs, instead of 112 B per lane
+        // through the vector L1, which is the busiest unit of this kernel.
+        auto finish = [&](const DrawDev& dp) __attribute__((always_inline)) {
+            // main.rs:183-218
+            if (has_uv && has_tb && dp.use_nm) {
+                double rgb[3];
+                sample_rgb(dp.nm, dp.nw, dp.nh, u * (double)(dp.nw - 1), v * (double)(dp.nh - 1), rgb, a.flags);
+                double mx = (div255(rgb[0]) * 2.0) - 1.0;
+                double my = (div255(rgb[1]) * 2.0) - 1.0;
+                double mz = (div255(rgb[2]) * 2.0) - 1.0;
+                double rx = (s.t[0] * mx + s.b[0] * my) + nx * mz;
+                double ry = (s.t[1] * mx + s.b[1] * my) + ny * mz;
+                double rz = (s.t[2] * mx + s.b[2] * my) + nz * mz;
+                normalize3(rx, ry, rz);
+                nx = rx; ny = ry; nz = rz;
+            }
+            // main.rs:221-247
+            double albedo[3];
+            if (has_uv) {
+                sample_rgb(dp.tex, dp.tw, dp.th, u * (double)(dp.tw - 1), v * (double)(dp.th - 1), albedo, a.flags);
+            } else {  // mod.rs:518-525 colour interpolation
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) albedo[c] = l1 * dp.vcol[c] + l2 * dp.vcol[c] + l3 * dp.vcol[c];
+            }
+            // main.rs:248-265
+            double d = fmax(dot3(nx, ny, nz, dp.light[0], dp.light[1], dp.light[2]), 0.0);
+    #pragma unroll
+            for (int c = 0; c < 3; ++c) col[c] = fmin(dp.ambient + (d * dp.intensity * albedo[c]), 255.0);
+            col[3] = 255.0;
+        };
+        if (__all(s.draw == 0u)) finish(a.draw0);  // kernel argument: scalar registers
+        else finish(a.draws[s.draw]);
     }
     a.rgba8[pix] = f64_as_u8(col[0]) | (f64_as_u8(col[1]) << 8) | (f64_as_u8(col[2]) << 16) |
                    (f64_as_u8(col[3]) << 24);
