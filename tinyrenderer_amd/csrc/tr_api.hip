@@ -81,7 +81,13 @@ struct tr_context {
     DrawDev* draw_table = nullptr;
     DrawDev draw0;                   // host copy of the frame's first draw (a kernel argument of the shade pass)
     uint32_t draw_cap = 4096;
-    unsigned long long* state_blk = nullptr;     // counters | cov_counters | flags, one allocation
+    unsigned long long* state_blk = nullptr;     // counters | cov_counters | flags, one allocation (current frame's half)
+    // Per-frame state is double-buffered: the shade pass of a frame zeroes the OTHER half (the
+    // previous frame's, dead since this frame's tr_clear), so the next tr_clear only swaps.
+    unsigned long long* state_both = nullptr;    // 2 x kStateWords
+    NanTable* nan_both = nullptr;                // 2
+    int state_idx = 0;
+    bool other_state_clean = false;
     unsigned long long* counters = nullptr;      // kCounterSlots x 8: [0] samples [1] fragments
     unsigned long long* cov_counters = nullptr;  // kCounterSlots x 8: [0] covered pixels
     uint32_t* flags = nullptr;
@@ -206,6 +212,17 @@ int ensure_scratch(tr_context* c, double** p, size_t* cap, size_t need) {
     return TR_OK;
 }
 
+constexpr uint32_t kStateWords = 2 * kCounterSlots * 8 + 8;  // u64 words of one half of the per-frame state
+
+void use_state(tr_context* c, int idx) {
+    c->state_idx = idx;
+    c->state_blk = c->state_both + (size_t)idx * kStateWords;
+    c->counters = c->state_blk;
+    c->cov_counters = c->state_blk + kCounterSlots * 8;
+    c->flags = (uint32_t*)(c->state_blk + 2 * kCounterSlots * 8);
+    c->nan = c->nan_both + idx;
+}
+
 constexpr int kRasterBlocks = 4096;
 constexpr int kRowBinBlocks = 1024;
 constexpr int kScanlineBlocks = 2048;
@@ -235,6 +252,9 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.live_cap = kChunkLiveCap;
     ra.use_live = 0;
     ra.rec_ready = 0;
+    ra.clean_state = nullptr;
+    ra.clean_words = 0;
+    ra.clean_nan = nullptr;
     ra.debug = 0;
     ra.trace = nullptr;
     ra.trace_cap = 0;
@@ -270,6 +290,12 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
             if (FILE* f = std::fopen(fn.c_str(), "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f); std::fclose(f); }
         }
     } dump{c, pass, trace_path, trace_buf};
+    if (pass == 1) {
+        ra.clean_state = c->state_both + (size_t)(1 - c->state_idx) * kStateWords;
+        ra.clean_words = kStateWords;
+        ra.clean_nan = c->nan_both + (1 - c->state_idx);
+        c->other_state_clean = true;
+    }
     if (pass == 0) {
         if (c->precheck) hipLaunchKernelGGL((k_raster<0, true>), grid, block, 0, c->stream, ra);
         else hipLaunchKernelGGL((k_raster<0, false>), grid, block, 0, c->stream, ra);
@@ -453,10 +479,9 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     c->wkey = c->planes + npix;
     if (hipMalloc(&c->rgba8, npix * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMalloc(&c->draw_table, c->draw_cap * sizeof(DrawDev)) != hipSuccess) return bail(TR_ERR_OOM);
-    if (hipMalloc(&c->state_blk, (2 * kCounterSlots * 8 + 8) * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
-    c->counters = c->state_blk;
-    c->cov_counters = c->state_blk + kCounterSlots * 8;
-    c->flags = (uint32_t*)(c->state_blk + 2 * kCounterSlots * 8);
+    if (hipMalloc(&c->state_both, 2 * (size_t)kStateWords * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->nan_both, 2 * sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
+    use_state(c, 0);
     c->tiles_x = (width + kTile - 1) / kTile;
     c->tiles_y = (height + kTile - 1) / kTile;
     {
@@ -469,7 +494,6 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         if (hipMalloc(&c->tile_list, (size_t)c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     }
-    if (hipMalloc(&c->nan, sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMalloc(&c->ticket, 64) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMemsetAsync(c->ticket, 0, 64, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     {
@@ -510,7 +534,7 @@ void tr_destroy(tr_context* c) {
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
     (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
-    (void)hipFree(c->draw_table); (void)hipFree(c->state_blk); (void)hipFree(c->nan);
+    (void)hipFree(c->draw_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -523,11 +547,17 @@ int tr_clear(tr_context* c) {
     TR_HIP(c, hipSetDevice(c->device));
     ProfScope ps(c, ST_CLEAR);
     size_t npix = (size_t)c->W * c->H;
-    {   // counters, covered-pixel counters, status flags, NaN table, scanline prefix: one launch
-        const uint32_t n_words = 2 * kCounterSlots * 8 + 8;
-        hipLaunchKernelGGL(k_clear_state, dim3((n_words + 255) / 256), dim3(256), 0, c->stream, c->state_blk, n_words,
-                           c->nan, c->half_off);
-        TR_HIP(c, hipGetLastError());
+    {   // counters, covered-pixel counters, status flags, NaN table: the other half of the state,
+        // which the last shade pass has already zeroed unless no resolve happened since the last clear
+        const int other = 1 - c->state_idx;
+        if (!c->other_state_clean) {
+            hipLaunchKernelGGL(k_clear_state, dim3((kStateWords + 255) / 256), dim3(256), 0, c->stream,
+                               c->state_both + (size_t)other * kStateWords, (uint32_t)kStateWords, c->nan_both + other,
+                               c->half_off);
+            TR_HIP(c, hipGetLastError());
+        }
+        use_state(c, other);
+        c->other_state_clean = false;
     }
     if (c->mode == 1) {
         // tile raster: no plane is cleared; every non-empty tile is rewritten, empty ones are never read
@@ -892,6 +922,7 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.cov_counters = c->cov_counters;
         sa.blk_touched = c->blk_flags; sa.blk_painted = c->blk_flags + c->n_blk;
         sa.draw0 = c->draw0;
+
         sa.skip_clean = (sa.self_clean && c->skip_clean) ? 1 : 0;
         if (c->cov_dirty)  // a second resolve of the same frame: tr_clear zeroes them otherwise
             TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));

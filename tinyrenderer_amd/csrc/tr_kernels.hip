@@ -515,6 +515,11 @@ struct RasterArgs {
     uint32_t live_cap;          // chunks beyond this are always treated as live
     int use_live;               // winner pass: skip chunks the depth pass found dead
     int rec_ready;              // depth pass: k_scanlines already built this range's records
+    // winner pass: the OTHER half of the double-buffered per-frame state (the previous frame's, dead
+    // since this frame's tr_clear) is zeroed on the side, so that the next tr_clear is a pointer swap
+    unsigned long long* clean_state;
+    uint32_t clean_words;
+    NanTable* clean_nan;
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
     unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
                                 // ticks, samples | block << 32)
@@ -659,6 +664,16 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     const uint32_t c_lo = s_begin / 64u;
     const uint32_t c_hi = (uint32_t)(((unsigned long long)s_end + 63ull) / 64ull);
     unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
+    if (PASS == 1 && a.clean_state) {
+        for (uint32_t w = blockIdx.x * (uint32_t)kRasterThreads + threadIdx.x; w < a.clean_words;
+             w += gridDim.x * (uint32_t)kRasterThreads)
+            a.clean_state[w] = 0ull;
+        if (blockIdx.x == 0 && threadIdx.x < kNanSlots) {
+            a.clean_nan->pix[threadIdx.x] = kNanEmpty;
+            a.clean_nan->first_nan[threadIdx.x] = kKeyNone;
+            a.clean_nan->first_any[threadIdx.x] = kKeyNone;
+        }
+    }
     bool nan_active = false;
     if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
 
