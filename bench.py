@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-frames", type=int, default=30)
-    ap.add_argument("--contexts", type=int, default=int(os.environ.get("TR_BENCH_CONTEXTS", "2")),
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("TR_BENCH_CONTEXTS", "4")),
                     help="render contexts (HIP streams) used round-robin: frames of successive steps overlap")
     args = ap.parse_args()
 

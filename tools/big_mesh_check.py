@@ -39,6 +39,9 @@ def main():
         st.resolve(_ffi.TR_OUT_RGBA8)
         st.synchronize()
         times.append(time.perf_counter() - t0)
+        # (reading the flags settles buffer growth: in row mode an overflowing frame is otherwise
+        # redone only at the next read-back, and the loop would time frames that drew nothing)
+        flags = st.status_flags()
     print("frame ms:", [round(t * 1e3, 2) for t in times], "flags", hex(st.status_flags()), st.counters(), flush=True)
     key = st.winner_keys()
     present = st.present()
