@@ -166,9 +166,36 @@ class ModelRendererState {
 // src/model_renderer/mod.rs:210-219
 inline void clear_screen(ModelRendererState& state) { state.check(tr_clear(state.context()), "tr_clear"); }
 
+// ---- EXTENSION shaders (tr_shade_ext in tinyrenderer_hip.h; the reference has only the shader of
+// main.rs:146-267): Gouraud / Phong switch, specular map, shadow map.
+class ShadowMap {  // the z plane of a state in which the scene was drawn from the light
+  public:
+    explicit ShadowMap(ModelRendererState& light_state) {
+        light_state.check(tr_shadow_map_create(light_state.context(), &map_), "tr_shadow_map_create");
+    }
+    ShadowMap(const ShadowMap&) = delete;
+    ShadowMap& operator=(const ShadowMap&) = delete;
+    ~ShadowMap() { tr_shadow_map_destroy(map_); }
+    const tr_shadow_map* handle() const { return map_; }
+
+  private:
+    tr_shadow_map* map_ = nullptr;
+};
+
+struct ShadeExt {
+    int model = TR_SHADE_REFERENCE;
+    const RgbaImage* specular_map = nullptr;  // flipped like the other textures; channel 0 = exponent
+    double shininess = 16.0, specular_strength = 0.6;
+    const ShadowMap* shadow = nullptr;
+    Matrix4 shadow_from_view = Matrix4::identity();  // light viewport * light pmv * inverse(viewport * pmv)
+    double shadow_bias = 0.0, shadow_dim = 0.3;
+};
+
 // render_mesh_component(state, &mesh, VS, FS) (mod.rs:225-230) with the closure pair replaced by
 // `shader`; takes the MeshComponent so the textures the closures capture (main.rs:140-141) come along.
-inline void render_mesh_component(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader) {
+// `ext` (no counterpart in the reference) selects an extension shader.
+inline void render_mesh_component(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader,
+                                  const ShadeExt* ext = nullptr) {
     tr_draw_params p{};
     const Matrix4 pmv = shader.perspective_matrix * shader.model_view_matrix;  // main.rs:152-153
     for (int i = 0; i < 16; ++i) {
@@ -182,7 +209,20 @@ inline void render_mesh_component(ModelRendererState& state, const MeshComponent
     p.use_normal_map = shader.use_normal_map ? 1 : 0;
     p.diffuse = state.texture_handle(mesh_component.texture);
     p.normal_map = state.texture_handle(mesh_component.normal_map);
-    state.check(tr_draw(state.context(), state.mesh_handle(mesh_component.mesh), &p), "tr_draw");
+    if (!ext) {
+        state.check(tr_draw(state.context(), state.mesh_handle(mesh_component.mesh), &p), "tr_draw");
+        return;
+    }
+    tr_shade_ext x{};
+    x.model = ext->model;
+    x.specular_map = ext->specular_map ? state.texture_handle(*ext->specular_map) : nullptr;
+    x.shininess = ext->shininess;
+    x.specular_strength = ext->specular_strength;
+    x.shadow = ext->shadow ? ext->shadow->handle() : nullptr;
+    for (int i = 0; i < 16; ++i) x.shadow_from_view[i] = ext->shadow_from_view.m[i];
+    x.shadow_bias = ext->shadow_bias;
+    x.shadow_dim = ext->shadow_dim;
+    state.check(tr_draw_ext(state.context(), state.mesh_handle(mesh_component.mesh), &p, &x), "tr_draw_ext");
 }
 
 }  // namespace tinyrenderer

@@ -120,6 +120,41 @@ typedef struct tr_draw_params {
  * because colour = shade(first sample in draw order whose depth equals the final minimum)). */
 int tr_draw(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params);
 
+/* ---- EXTENSION shaders: no counterpart in the reference, whose only shader pair is the one above.
+ * They exist because the build's brief (BASELINE.json north_star, configs[1]) names them; they are
+ * defined by this library and its CPU restatement (oracle/, `ora_render_mesh_component_ext`) and are
+ * checked GPU-against-CPU only.  With `ext` NULL, or model TR_SHADE_REFERENCE and no shadow map,
+ * tr_draw_ext IS tr_draw.  For a pixel with unit normal n (normal-mapped as in the reference), light
+ * direction l, albedo a:
+ *   diff  = max(n.l, 0)                       (Gouraud: max(n_c.l, 0) of the three unit vertex normals,
+ *                                              interpolated with the pixel's barycentrics)
+ *   spec  = pow(max((2 (n.l) n - l).z, 0), e)  (Phong only; e = channel 0 of the specular map at the
+ *                                              pixel's uv, sampled like the other textures, else `shininess`)
+ *   lit   = shadow_dim if the pixel's position, taken to the light frame by `shadow_from_view`
+ *           (column-major; perspective-divided; rounded to a pixel like every sample), lies on a
+ *           non-empty pixel of the shadow map whose z is smaller than the pixel's by more than
+ *           `shadow_bias`; else 1
+ *   rgb_c = min(ambient + (lit * (diff * intensity + specular_strength * spec)) * a_c, 255)
+ * tr_shadow_map_create snapshots the z plane of a context in which the scene was drawn from the
+ * light (any size); the map is independent of that context afterwards and may serve any number of
+ * frames on the same device. */
+enum { TR_SHADE_REFERENCE = 0, TR_SHADE_GOURAUD = 1, TR_SHADE_PHONG = 2 };
+typedef struct tr_shadow_map tr_shadow_map;
+typedef struct tr_shade_ext {
+    int32_t model;                  /* TR_SHADE_* */
+    int32_t reserved;
+    const tr_texture* specular_map; /* Phong exponent map or NULL */
+    double shininess;
+    double specular_strength;
+    const tr_shadow_map* shadow;    /* NULL = no shadow test */
+    double shadow_from_view[16];    /* light_viewport * light_pmv * inverse(viewport * pmv) of this draw */
+    double shadow_bias;
+    double shadow_dim;
+} tr_shade_ext;
+int tr_shadow_map_create(tr_context* light_ctx, tr_shadow_map** out_map);
+void tr_shadow_map_destroy(tr_shadow_map* map);
+int tr_draw_ext(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params, const tr_shade_ext* ext);
+
 /* No reference analogue (the reference shades inside the z-test): selects the winning sample per
  * pixel over all draws since tr_clear and runs the deferred shade.  out_mask selects which
  * planes are written besides RGBA8 (TR_OUT_*).  With TR_OUT_RGBA8 alone (the fast path) the

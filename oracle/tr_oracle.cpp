@@ -330,10 +330,38 @@ struct VSR {  // model_renderer/mod.rs:556-564 VertexShaderResult
     double color[4];
 };
 
+// EXTENSION shaders: no counterpart in the reference (its only shader pair is main.rs:146-267).
+// They are defined in include/tinyrenderer_hip.h (tr_shade_ext); this is their CPU statement, used
+// to check the GPU against (self-consistency, not reference parity).  ext == nullptr, or model 0
+// without a shadow map, leaves the reference's fragment shader untouched.
+struct OraShaderExt {
+    int32_t model;  // 0 reference, 1 Gouraud, 2 Phong
+    int32_t _pad;
+    const OraImage* specular_map;  // already flipped, or nullptr
+    double shininess;
+    double specular_strength;
+    const double* shadow;  // light-view z buffer in the reference layout ([x*H + y]) or nullptr
+    int64_t shadow_w, shadow_h;
+    double shadow_from_view[16];  // column-major
+    double shadow_bias;
+    double shadow_dim;
+};
+
+static int render_impl(OraState* st, const OraMesh* mesh, const OraShader* sh, const OraShaderExt* ext);
+
 // model_renderer/mod.rs:225-475.  Returns 0, or 1 if the reference would have
 // panicked (unwrap of an Err / out-of-bounds texture index); rendering stops at
 // that point like the panic would.
 int ora_render_mesh_component(OraState* st, const OraMesh* mesh, const OraShader* sh) {
+    return render_impl(st, mesh, sh, nullptr);
+}
+int ora_render_mesh_component_ext(OraState* st, const OraMesh* mesh, const OraShader* sh, const OraShaderExt* ext) {
+    return render_impl(st, mesh, sh, ext);
+}
+
+}  // extern "C"
+
+static int render_impl(OraState* st, const OraMesh* mesh, const OraShader* sh, const OraShaderExt* ext) {
     const int64_t frame_width = st->w, frame_height = st->h;
     const M4 perspective_matrix = load_m4(sh->perspective);
     const M4 model_view_matrix = load_m4(sh->model_view);
@@ -400,7 +428,9 @@ int ora_render_mesh_component(OraState* st, const OraMesh* mesh, const OraShader
     int status = 0;
     auto fragment_shader = [&](bool has_tbt, const V4& t_vector, const V4& bt_vector,
                                const V3& normal_interp, bool has_uv, const UV& uv_interp,
-                               const double color_interp[4], double out_color[4]) -> bool {
+                               const double color_interp[4], double out_color[4],
+                               // (extension inputs: barycentrics, vertex normals, viewport position)
+                               const double bary[3], const V4* vertex_normals, const V3& position) -> bool {
         V3 normal_vector = normal_interp;
         if (has_uv && has_tbt && sh->use_normal_map) {  // :183-216
             const NdImage& nm = sh->normal_map->img;
@@ -436,6 +466,48 @@ int ora_render_mesh_component(OraState* st, const OraMesh* mesh, const OraShader
         double diffuse_proportion = rmax(dot3(normal_vector, to_light_vec), 0.0);
         double light_intensity = sh->light_intensity;
         double ambient_light = sh->ambient_light;
+        if (ext && (ext->model != 0 || ext->shadow)) {  // ---- extension, see OraShaderExt
+            double d = diffuse_proportion;
+            if (ext->model == 1) {
+                double g[3];
+                for (int c = 0; c < 3; ++c) {
+                    V3 vn = normalize3(V3{vertex_normals[c].x, vertex_normals[c].y, vertex_normals[c].z});
+                    g[c] = rmax(dot3(vn, to_light_vec), 0.0);
+                }
+                d = bary[0] * g[0] + bary[1] * g[1] + bary[2] * g[2];
+            }
+            double spec = 0.0;
+            if (ext->model == 2) {
+                double ndl = dot3(normal_vector, to_light_vec);
+                double rz = (2.0 * ndl) * normal_vector.z - to_light_vec.z;
+                double ex = ext->shininess;
+                if (ext->specular_map && has_uv) {
+                    const NdImage& sm = ext->specular_map->img;
+                    double srgb[4];
+                    if (!sample_nd_img(sm, uv_interp.u * (double)(sm.w - 1), uv_interp.v * (double)(sm.h - 1), srgb)) {
+                        st->n_tex_panic++;
+                        status = 1;
+                        return false;
+                    }
+                    ex = srgb[0];
+                }
+                spec = std::pow(rmax(rz, 0.0), ex);
+            }
+            double lit = 1.0;
+            if (ext->shadow) {
+                V4 q = mat4_mul_vec4(load_m4(ext->shadow_from_view), V4{position.x, position.y, position.z, 1.0});
+                double xl = q.x / q.w, yl = q.y / q.w, zl = q.z / q.w;
+                int64_t ix = rust_as_i64(std::round(xl)), iy = rust_as_i64(std::round(yl));
+                if (ix >= 0 && ix <= ext->shadow_w - 1 && iy >= 0 && iy <= ext->shadow_h - 1) {
+                    double zm = ext->shadow[(size_t)(ix * ext->shadow_h + iy)];
+                    if (zm != -std::numeric_limits<double>::infinity() && -zl > zm + ext->shadow_bias) lit = ext->shadow_dim;
+                }
+            }
+            double term = lit * (d * light_intensity + ext->specular_strength * spec);
+            for (int c = 0; c < 3; ++c) out_color[c] = rmin(ambient_light + (term * albedo[c]), 255.0);
+            out_color[3] = 255.0;
+            return true;
+        }
         for (int c = 0; c < 3; ++c)
             out_color[c] = rmin(ambient_light + (diffuse_proportion * light_intensity * albedo[c]), 255.0);
         out_color[3] = 255.0;
@@ -566,8 +638,10 @@ int ora_render_mesh_component(OraState* st, const OraMesh* mesh, const OraShader
                         for (int c = 0; c < 4; ++c)
                             color_interp[c] = l1 * vsr1.color[c] + l2 * vsr2.color[c] + l3 * vsr3.color[c];
                         double color[4];
+                        const double bary[3] = {l1, l2, l3};
+                        const V4 vertex_normals[3] = {n1, n2, n3};
                         if (!fragment_shader(has_tbt, t_vector, bt_vector, normal_interp, has_uv, uvi,
-                                             color_interp, color))
+                                             color_interp, color, bary, vertex_normals, p))
                             return false;
                         for (int c = 0; c < 4; ++c) st->frame_buffer.at(x, y, c) = color[c];  // :414-416
                     }
@@ -596,6 +670,8 @@ int ora_render_mesh_component(OraState* st, const OraMesh* mesh, const OraShader
     }
     return status;
 }
+
+extern "C" {
 
 // Buffers in the reference's own layout: element [x,y,c] at ((x*H)+y)*C+c.
 const double* ora_z_buffer(const OraState* s) { return s->z_buffer.d.data(); }

@@ -26,6 +26,13 @@ class OraShader(C.Structure):
                 ("texture", C.c_void_p), ("normal_map", C.c_void_p)]
 
 
+class OraShaderExt(C.Structure):  # extension shaders (no counterpart in the reference)
+    _fields_ = [("model", C.c_int32), ("_pad", C.c_int32), ("specular_map", C.c_void_p),
+                ("shininess", C.c_double), ("specular_strength", C.c_double),
+                ("shadow", C.c_void_p), ("shadow_w", C.c_int64), ("shadow_h", C.c_int64),
+                ("shadow_from_view", C.c_double * 16), ("shadow_bias", C.c_double), ("shadow_dim", C.c_double)]
+
+
 _lib = None
 
 
@@ -52,6 +59,8 @@ def load(build_if_missing=True):
     lib.ora_sample_nd_img.argtypes = [vp, C.c_double, C.c_double, pd]
     lib.ora_render_mesh_component.restype = C.c_int
     lib.ora_render_mesh_component.argtypes = [vp, C.POINTER(OraMesh), C.POINTER(OraShader)]
+    lib.ora_render_mesh_component_ext.restype = C.c_int
+    lib.ora_render_mesh_component_ext.argtypes = [vp, C.POINTER(OraMesh), C.POINTER(OraShader), C.POINTER(OraShaderExt)]
     for n in ("ora_z_buffer", "ora_frame_buffer"):
         getattr(lib, n).restype = pd
         getattr(lib, n).argtypes = [vp]
@@ -110,8 +119,9 @@ class OracleState:
     def clear_screen(self):
         self.lib.ora_clear_screen(self.ptr)
 
-    def render_mesh_component(self, obj, shader, texture, normal_map):
-        """obj: helpers.Object; shader: model_renderer.BuiltinShader; texture/normal_map: OracleImage."""
+    def render_mesh_component(self, obj, shader, texture, normal_map, ext=None, specular_map=None):
+        """obj: helpers.Object; shader: model_renderer.BuiltinShader; texture/normal_map: OracleImage;
+        ext: model_renderer.ShadeExt (extension shaders) with specular_map as an OracleImage."""
         m = OraMesh()
         v, t, n, tri = obj.vertices, obj.tex_vertices, obj.normals, obj.triangles
         m.positions, m.normals, m.uvw, m.idx = v.ctypes.data, n.ctypes.data, t.ctypes.data, tri.ctypes.data
@@ -126,7 +136,19 @@ class OracleState:
         s.use_normal_map = 1 if shader.use_normal_map else 0
         s.texture = texture.ptr if texture is not None else None
         s.normal_map = normal_map.ptr if normal_map is not None else None
-        return self.lib.ora_render_mesh_component(self.ptr, C.byref(m), C.byref(s))
+        if ext is None:
+            return self.lib.ora_render_mesh_component(self.ptr, C.byref(m), C.byref(s))
+        x = OraShaderExt()
+        x.model = ext.model
+        x.specular_map = specular_map.ptr if specular_map is not None else None
+        x.shininess, x.specular_strength = ext.shininess, ext.specular_strength
+        z = None
+        if ext.shadow is not None:
+            z = np.ascontiguousarray(ext.shadow.z_reference(), dtype=np.float64)
+            x.shadow, x.shadow_w, x.shadow_h = z.ctypes.data, z.shape[0], z.shape[1]
+        x.shadow_from_view[:] = _cm16(ext.shadow_from_view)
+        x.shadow_bias, x.shadow_dim = ext.shadow_bias, ext.shadow_dim
+        return self.lib.ora_render_mesh_component_ext(self.ptr, C.byref(m), C.byref(s), C.byref(x))
 
     def _arr(self, fn, dtype, comps):
         p = fn(self.ptr)

@@ -33,12 +33,16 @@ def oracle_render(oracle, W, H, draws):
     imgs = {}
     tri_base = []
     base = 0
-    for mc, sh in draws:
-        for img in (mc.texture, mc.normal_map):
+    for draw in draws:
+        mc, sh = draw[0], draw[1]
+        ext = draw[2] if len(draw) > 2 else None  # (mc, shader, ShadeExt): extension shaders
+        spec = ext.specular_map if ext is not None else None
+        for img in (mc.texture, mc.normal_map, spec):
             if img is not None and id(img) not in imgs:
                 # the oracle flips by itself (model_renderer/mod.rs:40-41): hand it the un-flipped image
                 imgs[id(img)] = oracle.OracleImage(img[::-1], flip=True)
-        rc = st.render_mesh_component(mc.mesh, sh, imgs.get(id(mc.texture)), imgs.get(id(mc.normal_map)))
+        rc = st.render_mesh_component(mc.mesh, sh, imgs.get(id(mc.texture)), imgs.get(id(mc.normal_map)),
+                                      ext=ext, specular_map=imgs.get(id(spec)))
         assert rc == 0, "oracle: the reference would have panicked on this scene"
         tri_base.append(base)
         base += mc.mesh.triangles.shape[0]
@@ -56,8 +60,8 @@ def gpu_render(W, H, draws, device=0, mode=None, band=None):
         clear_screen(st)
         if band is not None:
             st.set_band(*band)
-        for mc, sh in draws:
-            render_mesh_component(st, mc, sh)
+        for draw in draws:
+            render_mesh_component(st, draw[0], draw[1], draw[2] if len(draw) > 2 else None)
         st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z | _ffi.TR_OUT_TRI_ID | _ffi.TR_OUT_RGBA_F64)
         out = {"z": st.z_buffer[..., 0], "fb": st.frame_buffer, "key": st.winner_keys(),
                "seq": st.triangle_ids().astype(np.int64), "present": st.present(),

@@ -30,6 +30,7 @@ TR_RASTER_GLOBAL, TR_RASTER_TILE, TR_RASTER_ROWS = 0, 1, 2
 TR_LAYOUT_ROW_MAJOR = 0
 TR_LAYOUT_REFERENCE = 1
 TR_OUT_RGBA8, TR_OUT_Z, TR_OUT_TRI_ID, TR_OUT_RGBA_F64, TR_OUT_KEY = 1, 2, 4, 8, 16
+TR_SHADE_REFERENCE, TR_SHADE_GOURAUD, TR_SHADE_PHONG = 0, 1, 2  # extension shaders (tr_draw_ext)
 
 # Every symbol include/tinyrenderer_hip.h declares (checked by tests/test_abi.py).
 EXPORTS = [
@@ -41,6 +42,7 @@ EXPORTS = [
     "tr_set_raster_mode", "tr_obj_load", "tr_obj_parse", "tr_obj_counts", "tr_obj_positions", "tr_obj_uvw",
     "tr_obj_normals", "tr_obj_indices", "tr_obj_free", "tr_image_load_rgba8", "tr_image_size", "tr_image_data",
     "tr_image_free", "tr_load_error", "tr_image_write_png", "tr_selftest_arithmetic",
+    "tr_draw_ext", "tr_shadow_map_create", "tr_shadow_map_destroy",
 ]
 
 
@@ -56,6 +58,21 @@ class DrawParams(C.Structure):
         ("reserved", C.c_int32),
         ("diffuse", C.c_void_p),
         ("normal_map", C.c_void_p),
+    ]
+
+
+class ShadeExt(C.Structure):
+    """tr_shade_ext: extension shaders, no counterpart in the reference."""
+    _fields_ = [
+        ("model", C.c_int32),
+        ("reserved", C.c_int32),
+        ("specular_map", C.c_void_p),
+        ("shininess", C.c_double),
+        ("specular_strength", C.c_double),
+        ("shadow", C.c_void_p),
+        ("shadow_from_view", C.c_double * 16),
+        ("shadow_bias", C.c_double),
+        ("shadow_dim", C.c_double),
     ]
 
 
@@ -116,6 +133,9 @@ def load():
         "tr_load_error": (C.c_char_p, []),
         "tr_image_write_png": (i32, [C.c_char_p, vp, i32, i32]),
         "tr_selftest_arithmetic": (i32, [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+        "tr_draw_ext": (i32, [vp, vp, C.POINTER(DrawParams), C.POINTER(ShadeExt)]),
+        "tr_shadow_map_create": (i32, [vp, C.POINTER(vp)]),
+        "tr_shadow_map_destroy": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

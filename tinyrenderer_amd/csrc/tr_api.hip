@@ -21,6 +21,12 @@ struct tr_texture {
     int w = 0, h = 0;
 };
 
+struct tr_shadow_map {  // extension: a light-view z plane (tr_shadow_map_create)
+    double* dev = nullptr;
+    int w = 0, h = 0;
+    int device = 0;
+};
+
 struct tr_mesh {
     double* pos = nullptr;
     double* nrm = nullptr;
@@ -79,6 +85,8 @@ struct tr_context {
     double* nout = nullptr;
     size_t ndc_cap = 0, nout_cap = 0;
     DrawDev* draw_table = nullptr;
+    DrawExt* ext_table = nullptr;    // extension shaders: allocated with the first tr_draw_ext that names one
+    bool frame_has_ext = false;      // some draw since tr_clear uses an extension: k_shade<true>
     DrawDev draw0;                   // host copy of the frame's first draw (a kernel argument of the shade pass)
     uint32_t draw_cap = 4096;
     unsigned long long* state_blk = nullptr;     // counters | cov_counters | flags, one allocation (current frame's half)
@@ -428,7 +436,7 @@ int read_plane(tr_context* c, const T* dev, T* out, int layout, int comps) {
 
 extern "C" {
 
-const char* tr_version(void) { return "tinyrenderer_hip abi=2 arch=gfx950 fp=f64 contract=off"; }
+const char* tr_version(void) { return "tinyrenderer_hip abi=3 arch=gfx950 fp=f64 contract=off"; }
 
 const char* tr_last_error(const tr_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -534,7 +542,7 @@ void tr_destroy(tr_context* c) {
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
     (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
-    (void)hipFree(c->draw_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
+    (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -578,6 +586,7 @@ int tr_clear(tr_context* c) {
     c->draw_count = 0;
     c->resolved = false;
     c->resolved_mask = 0;
+    c->frame_has_ext = false;
     return TR_OK;
 }
 
@@ -668,7 +677,37 @@ int tr_texture_destroy(tr_context* c, tr_texture* t) {
     return TR_OK;
 }
 
-int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
+int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) { return tr_draw_ext(c, mesh, p, nullptr); }
+
+int tr_shadow_map_create(tr_context* light, tr_shadow_map** out) {
+    if (!light || !out) return TR_ERR_INVALID;
+    *out = nullptr;
+    TR_HIP(light, hipSetDevice(light->device));
+    int rc = need_plane(light, TR_OUT_Z);
+    if (rc != TR_OK) return rc;
+    tr_shadow_map* m = new (std::nothrow) tr_shadow_map();
+    if (!m) return fail(light, TR_ERR_OOM, "shadow map");
+    m->w = light->W; m->h = light->H; m->device = light->device;
+    const size_t bytes = (size_t)m->w * m->h * sizeof(double);
+    if (hipMalloc(&m->dev, bytes) != hipSuccess) { delete m; return fail(light, TR_ERR_OOM, "shadow map"); }
+    if (hipMemcpyAsync(m->dev, light->z_out, bytes, hipMemcpyDeviceToDevice, light->stream) != hipSuccess ||
+        hipStreamSynchronize(light->stream) != hipSuccess) {
+        (void)hipFree(m->dev);
+        delete m;
+        return fail(light, TR_ERR_HIP, "shadow map copy");
+    }
+    *out = m;
+    return TR_OK;
+}
+
+void tr_shadow_map_destroy(tr_shadow_map* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipFree(m->dev);
+    delete m;
+}
+
+int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, const tr_shade_ext* x) {
     if (!c || !mesh || !p) return TR_ERR_INVALID;
     if (mesh->any_uv && (!p->diffuse || (p->use_normal_map && !p->normal_map)))
         return fail(c, TR_ERR_INVALID, "mesh has texture coordinates but a texture is missing");
@@ -678,6 +717,31 @@ int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) {
     TR_HIP(c, hipSetDevice(c->device));
     c->resolved = false;
     c->resolved_mask = 0;
+    if (x) {
+        if (x->model < TR_SHADE_REFERENCE || x->model > TR_SHADE_PHONG) return fail(c, TR_ERR_INVALID, "unknown shading model");
+        if (x->shadow && x->shadow->device != c->device) return fail(c, TR_ERR_INVALID, "shadow map lives on another device");
+    }
+    const bool ext_draw = x && (x->model != TR_SHADE_REFERENCE || x->shadow);
+    if (ext_draw || c->ext_table) {
+        // (once the table exists every draw writes its entry: a frame may mix both kinds)
+        if (!c->ext_table) {
+            TR_HIP(c, hipMalloc(&c->ext_table, c->draw_cap * sizeof(DrawExt)));
+            TR_HIP(c, hipMemsetAsync(c->ext_table, 0, c->draw_cap * sizeof(DrawExt), c->stream));
+        }
+        DrawExt e;
+        std::memset(&e, 0, sizeof(e));
+        if (ext_draw) {
+            e.model = x->model;
+            if (x->specular_map) { e.spec = x->specular_map->dev; e.sw = x->specular_map->w; e.sh = x->specular_map->h; }
+            if (x->shadow) { e.shadow = x->shadow->dev; e.mw = x->shadow->w; e.mh = x->shadow->h; }
+            e.shininess = x->shininess; e.strength = x->specular_strength;
+            e.bias = x->shadow_bias; e.dim = x->shadow_dim;
+            std::memcpy(e.to_light.m, x->shadow_from_view, sizeof(e.to_light.m));
+            c->frame_has_ext = true;
+        }
+        hipLaunchKernelGGL(k_put_ext, dim3(1), dim3(64), 0, c->stream, e, c->ext_table, c->draw_count);
+        TR_HIP(c, hipGetLastError());
+    }
     if (mesh->n_tris == 0) {
         c->draw_count++;
         return TR_OK;
@@ -927,8 +991,10 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         if (c->cov_dirty)  // a second resolve of the same frame: tr_clear zeroes them otherwise
             TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
         c->cov_dirty = true;
-        hipLaunchKernelGGL(k_shade, dim3((c->W + kShadeBW - 1) / kShadeBW, (c->H + kShadeBH - 1) / kShadeBH), dim3(256),
-                           0, c->stream, sa);
+        sa.ext = c->ext_table;
+        const dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, (c->H + kShadeBH - 1) / kShadeBH);
+        if (c->frame_has_ext) hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(256), 0, c->stream, sa);
+        else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(256), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }
     if (c->mode != 1 && out_mask == TR_OUT_RGBA8) {

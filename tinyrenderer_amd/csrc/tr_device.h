@@ -65,6 +65,21 @@ struct DrawDev {
     int32_t pad;
 };
 
+// EXTENSION shaders (no counterpart in the reference, whose only shader is main.rs:146-267): per
+// draw, read by k_shade<true> only.  model 0 with no shadow map is the reference's formula.
+struct DrawExt {
+    int32_t model;          // 0 reference, 1 Gouraud (per-vertex diffuse), 2 Phong (adds a specular term)
+    int32_t sw, sh;         // specular map size
+    int32_t mw, mh;         // shadow map size
+    int32_t pad;
+    const uint32_t* spec;   // RGBA8 specular map (channel 0 = exponent) or nullptr
+    const double* shadow;   // light-view z plane (min of -z per pixel, -inf = empty), row-major, or nullptr
+    double shininess;       // exponent where there is no specular map (or no uv)
+    double strength;        // weight of the specular term
+    double bias, dim;       // shadow: in shadow iff dist > map + bias; lit terms are multiplied by dim there
+    Mat4 to_light;          // this frame's viewport space -> the light frame's viewport space
+};
+
 // Small side table for NaN-depth samples (SURVEY.md 7.1 caveat i): a NaN sample wins a
 // pixel iff it is the first sample to land on it in draw order.
 struct NanTable {

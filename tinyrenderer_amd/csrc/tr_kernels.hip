@@ -940,6 +940,7 @@ struct ShadeArgs {
     uint8_t* blk_painted;  // per block: rgba8 holds something other than the background
     int skip_clean;        // blocks neither touched nor painted are left alone (RGBA8-only resolve, global raster)
     DrawDev draw0;         // copy of draws[0]
+    const DrawExt* ext;    // k_shade<true>: per draw
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -985,6 +986,10 @@ __device__ __forceinline__ uint32_t f64_as_u8(double v) {
 }
 
 
+// EXT = false: the reference's shader, the tuned path of every parity test and of the benchmark.
+// EXT = true: a frame in which some draw asked for an extension shader (DrawExt); draws without one
+// still get the reference's formula, operation for operation.
+template <bool EXT>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const int x = blockIdx.x * kShadeBW + (threadIdx.x & (kShadeBW - 1));
     const int y = blockIdx.y * kShadeBH + (threadIdx.x / kShadeBW);
@@ -1092,6 +1097,49 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             }
             // main.rs:248-265
             double d = fmax(dot3(nx, ny, nz, dp.light[0], dp.light[1], dp.light[2]), 0.0);
+            if (EXT) {
+                const DrawExt& e = a.ext[s.draw];
+                if (e.model != 0 || e.shadow) {
+                    if (e.model == 1) {  // Gouraud: diffuse term at the vertices, interpolated
+                        double g[3];
+    #pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            double vx = s.n[c][0], vy = s.n[c][1], vz = s.n[c][2];
+                            normalize3(vx, vy, vz);
+                            g[c] = fmax(dot3(vx, vy, vz, dp.light[0], dp.light[1], dp.light[2]), 0.0);
+                        }
+                        d = l1 * g[0] + l2 * g[1] + l3 * g[2];
+                    }
+                    double spec = 0.0;
+                    if (e.model == 2) {  // Phong: reflected light direction against the view axis
+                        const double ndl = dot3(nx, ny, nz, dp.light[0], dp.light[1], dp.light[2]);
+                        const double rz = (2.0 * ndl) * nz - dp.light[2];
+                        double ex = e.shininess;
+                        if (e.spec && has_uv) {
+                            double srgb[3];
+                            sample_rgb(e.spec, e.sw, e.sh, u * (double)(e.sw - 1), v * (double)(e.sh - 1), srgb, a.flags);
+                            ex = srgb[0];
+                        }
+                        spec = pow(fmax(rz, 0.0), ex);
+                    }
+                    double lit = 1.0;
+                    if (e.shadow) {
+                        double q[4];
+                        mat4_mul_vec4(e.to_light, px, py, pz, 1.0, q);
+                        const double xl = q[0] / q[3], yl = q[1] / q[3], zl = q[2] / q[3];
+                        const int ix = pixel_coord(xl, e.mw), iy = pixel_coord(yl, e.mh);
+                        if (ix >= 0 && iy >= 0) {
+                            const double zm = e.shadow[(size_t)iy * (size_t)e.mw + (size_t)ix];
+                            if (zm != -__builtin_huge_val() && -zl > zm + e.bias) lit = e.dim;
+                        }
+                    }
+                    const double term = lit * (d * dp.intensity + e.strength * spec);
+    #pragma unroll
+                    for (int c = 0; c < 3; ++c) col[c] = fmin(dp.ambient + (term * albedo[c]), 255.0);
+                    col[3] = 255.0;
+                    return;
+                }
+            }
     #pragma unroll
             for (int c = 0; c < 3; ++c) col[c] = fmin(dp.ambient + (d * dp.intensity * albedo[c]), 255.0);
             col[3] = 255.0;
@@ -1108,6 +1156,13 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         double4 o = make_double4(col[0], col[1], col[2], col[3]);
         reinterpret_cast<double4*>(a.rgba_f64)[pix] = o;
     }
+}
+
+template __global__ void k_shade<false>(ShadeArgs);
+template __global__ void k_shade<true>(ShadeArgs);
+
+__global__ void k_put_ext(DrawExt e, DrawExt* table, uint32_t draw) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) table[draw] = e;
 }
 
 // =============================================================== misc fills

@@ -111,6 +111,77 @@ class BuiltinShader:
         return H.mat4_mul(self.perspective_matrix, self.model_view_matrix)
 
 
+class ShadowMap:
+    """EXTENSION (no counterpart in the reference): the z plane of a state in which the scene was
+    drawn from the light, snapshotted on the GPU (tr_shadow_map_create).  `keep_host_copy` also keeps
+    it as a (W, H) array in the reference layout, which is what the CPU restatement consumes."""
+
+    def __init__(self, light_state, keep_host_copy=False):
+        self._lib = light_state._lib
+        h = C.c_void_p()
+        _ffi.check(light_state._ctx, self._lib.tr_shadow_map_create(light_state._ctx, C.byref(h)), "tr_shadow_map_create")
+        self._handle = h
+        self.width, self.height = light_state.frame_width, light_state.frame_height
+        self.z_host = light_state.z_buffer[..., 0] if keep_host_copy else None
+
+    def z_reference(self):
+        if self.z_host is None:
+            raise ValueError("ShadowMap was created without keep_host_copy")
+        return self.z_host
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.tr_shadow_map_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostShadow:
+    """A shadow map that only lives on the host (for the CPU restatement): z in the reference layout."""
+
+    def __init__(self, z_wh):
+        self.z_host = np.ascontiguousarray(z_wh, dtype=np.float64)
+        self.width, self.height = self.z_host.shape
+
+    def z_reference(self):
+        return self.z_host
+
+
+class ShadeExt:
+    """EXTENSION shaders (tr_shade_ext in include/tinyrenderer_hip.h; the reference has only the
+    shader of main.rs:146-267): Gouraud / Phong switch, specular map, shadow map."""
+
+    def __init__(self, model=_ffi.TR_SHADE_REFERENCE, specular_map=None, shininess=16.0, specular_strength=0.6,
+                 shadow=None, shadow_from_view=None, shadow_bias=0.0, shadow_dim=0.3):
+        self.model = int(model)
+        self.specular_map = specular_map  # (H, W, 4) uint8, flipped like the other textures
+        self.shininess = float(shininess)
+        self.specular_strength = float(specular_strength)
+        self.shadow = shadow
+        self.shadow_from_view = (np.eye(4) if shadow_from_view is None else np.asarray(shadow_from_view, dtype=np.float64))
+        self.shadow_bias = float(shadow_bias)
+        self.shadow_dim = float(shadow_dim)
+
+
+def viewport_matrix(frame_width, frame_height):
+    """src/model_renderer/mod.rs:314-318: scale((W-1)/2, (H-1)/2, 1) * translate(1, 1, 0)."""
+    return H.mat4_mul(H.make_scale_matrix(((frame_width - 1) / 2.0, (frame_height - 1) / 2.0, 1.0)),
+                      H.make_translation_matrix((1.0, 1.0, 0.0)))
+
+
+def shadow_from_view(view_shader, frame_width, frame_height, light_shader, light_width, light_height):
+    """Matrix taking a viewport-space position of the camera frame to the light frame's viewport
+    space (extension): VP_l * PMV_l * inverse(VP * PMV)."""
+    cam = viewport_matrix(frame_width, frame_height) @ view_shader.pmv()
+    lit = viewport_matrix(light_width, light_height) @ light_shader.pmv()
+    return lit @ np.linalg.inv(cam)
+
+
 class ModelRendererState:
     """src/model_renderer/mod.rs:29-35,150-173.  `frame_buffer` / `z_buffer` are read back from
     the GPU on access, in the reference's (W, H, C) layout."""
@@ -255,12 +326,33 @@ def make_draw_params(state, shader, texture, normal_map):
     return p
 
 
-def render_mesh_component(model_renderer_state, mesh_component, shader):
+def make_shade_ext(state, ext):
+    x = _ffi.ShadeExt()
+    x.model = ext.model
+    x.specular_map = state._texture_handle(ext.specular_map)
+    x.shininess = ext.shininess
+    x.specular_strength = ext.specular_strength
+    if ext.shadow is not None:
+        if not isinstance(ext.shadow, ShadowMap):
+            raise TypeError("the GPU path needs a ShadowMap (tr_shadow_map_create)")
+        x.shadow = ext.shadow._handle
+    x.shadow_from_view[:] = [float(v) for v in ext.shadow_from_view.T.reshape(16)]  # column-major
+    x.shadow_bias = ext.shadow_bias
+    x.shadow_dim = ext.shadow_dim
+    return x
+
+
+def render_mesh_component(model_renderer_state, mesh_component, shader, ext=None):
     """`render_mesh_component(state, &mesh, VS, FS)` (src/model_renderer/mod.rs:225-230) with the
     closure pair replaced by `shader` (a BuiltinShader).  Takes the MeshComponent so the
     shader's texture / normal map (captured by the reference's closures, main.rs:140-141) come
-    along."""
+    along.  `ext` (a ShadeExt) selects an extension shader; the reference has none."""
     s = model_renderer_state
     p = make_draw_params(s, shader, mesh_component.texture, mesh_component.normal_map)
-    rc = s._lib.tr_draw(s._ctx, s._mesh_handle(mesh_component.mesh), C.byref(p))
-    _ffi.check(s._ctx, rc, "tr_draw")
+    if ext is None:
+        rc = s._lib.tr_draw(s._ctx, s._mesh_handle(mesh_component.mesh), C.byref(p))
+        _ffi.check(s._ctx, rc, "tr_draw")
+    else:
+        x = make_shade_ext(s, ext)
+        rc = s._lib.tr_draw_ext(s._ctx, s._mesh_handle(mesh_component.mesh), C.byref(p), C.byref(x))
+        _ffi.check(s._ctx, rc, "tr_draw_ext")

@@ -17,6 +17,13 @@ AFRICAN_HEAD_EYE_INNER = ("african_head/african_head_eye_inner.obj",
                           "african_head/african_head_eye_inner_nm_tangent.png")
 DIABLO = ("diablo_guy/diablo3_pose.obj", "diablo_guy/diablo3_pose_diffuse.png",
           "diablo_guy/diablo3_pose_nm_tangent.png")
+# specular maps (grey: the Phong exponent) for the EXTENSION shaders; the reference loads none of them
+SPECULAR = {"head": "african_head/african_head_spec.png", "diablo": "diablo_guy/diablo3_pose_spec.png"}
+
+
+def load_specular(name, asset_dir=None):
+    d = asset_dir or H.ASSET_DIR
+    return H.flip_vertically(H.load_rgba_img_from_file(os.path.join(d, SPECULAR[name])))
 
 
 def load_component(triple, asset_dir=None):
