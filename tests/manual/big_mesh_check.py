@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[3] rehearsal on one GPU: african_head subdivided `levels` times
 (2492 * 4**levels triangles), rendered whole at WxH, timed, and compared with the oracle.
-    python tools/big_mesh_check.py [levels=5] [W=1920] [H=1080] [mode=0] [oracle=1]"""
+    python tests/manual/big_mesh_check.py [levels=5] [W=1920] [H=1080] [mode=0] [oracle=1]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

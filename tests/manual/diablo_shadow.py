@@ -2,14 +2,14 @@
 """BASELINE.json configs[1]: diablo3_pose with normal + specular maps and a shadow-map pass at
 1024x1024 on one GPU.  The Phong / specular / shadow shaders are EXTENSIONS (the reference has none):
 the frame is compared with the build's own CPU statement of them (oracle/), visibility bit for bit,
-colour within 1 LSB.      python tools/diablo_shadow.py [W=1024] [H=1024] [map=1024] [out.png]"""
+colour within 1 LSB.      python tests/manual/diablo_shadow.py [W=1024] [H=1024] [map=1024] [out.png]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

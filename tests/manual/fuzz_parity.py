@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Longer fuzz run than the test suite's: random triangle soups (tests/test_gpu_parity._random_scene)
-of random sizes through every raster mode against the oracle.  python tools/fuzz_parity.py [n=100] [seed0=1000]"""
+of random sizes through every raster mode against the oracle.  python tests/manual/fuzz_parity.py [n=100] [seed0=1000]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
