@@ -73,7 +73,7 @@ struct tr_context {
     uint32_t n_bins_padded = 0;
     uint32_t ref_cap = 2u << 20;
     int nseg = 0;
-    uint8_t* blk_flags = nullptr;    // [0, n_blk): touched this frame, [n_blk, 2 n_blk): rgba8 not background
+    uint8_t* blk_flags = nullptr;    // per shade block [2 b]: touched this frame, [2 b + 1]: rgba8 not background
     uint32_t n_blk = 0;
     int blocks_x = 0;
     bool skip_clean = true;          // shade pass skips blocks that hold no key and are already background
@@ -366,7 +366,7 @@ int settle_row_overflow(tr_context* c) {
             c->counted_upto = 0;
             c->wkey_dirty = false;
             TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * (size_t)c->W * c->H * sizeof(unsigned long long), c->stream));
-            TR_HIP(c, hipMemsetAsync(c->blk_flags, 0, c->n_blk, c->stream));
+            TR_HIP(c, hipMemset2DAsync(c->blk_flags, 2, 0, 1, c->n_blk, c->stream));
             // k_clear_state's job for the NaN table was done at tr_clear; the row raster never touched it
         }
         int rc = tr_resolve(c, mask);
@@ -518,10 +518,11 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (const char* e = std::getenv("TR_SHADE_SKIP_CLEAN")) c->skip_clean = std::atoi(e) != 0;
     c->blocks_x = (width + kShadeBW - 1) / kShadeBW;
     c->n_blk = (uint32_t)c->blocks_x * (uint32_t)((height + kShadeBH - 1) / kShadeBH);
-    if (hipMalloc(&c->blk_flags, 2 * (size_t)c->n_blk) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->blk_flags, 2 * (size_t)c->n_blk + 8) != hipSuccess)  // (read as aligned dwords)
+        return bail(TR_ERR_OOM);
     // every block starts "painted": the first resolve writes the whole frame
-    if (hipMemsetAsync(c->blk_flags, 0, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
-    if (hipMemsetAsync(c->blk_flags + c->n_blk, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMemset2DAsync(c->blk_flags, 2, 0, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMemset2DAsync(c->blk_flags + 1, 2, 1, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->chunk_live, kChunkLiveCap) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMemsetAsync(c->chunk_live, 0, kChunkLiveCap, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->rec, (size_t)(c->rec_cap ? c->rec_cap : 1) * sizeof(ScanRec)) != hipSuccess) return bail(TR_ERR_OOM);
@@ -574,7 +575,7 @@ int tr_clear(tr_context* c) {
         // depth = "no sample yet", winner = none: both all-ones.  Skipped when the last resolve
         // already left the planes cleared (the shade pass wipes what it consumes).
         TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * npix * sizeof(unsigned long long), c->stream));
-        TR_HIP(c, hipMemsetAsync(c->blk_flags, 0, c->n_blk, c->stream));  // "touched" goes with the keys
+        TR_HIP(c, hipMemset2DAsync(c->blk_flags, 2, 0, 1, c->n_blk, c->stream));  // "touched" goes with the keys
         c->planes_clean = true;
     }
     c->wkey_dirty = false;
@@ -984,7 +985,7 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         sa.tiles_x = c->tiles_x;
         sa.W = c->W; sa.H = c->H; sa.out_mask = out_mask; sa.rgba8 = c->rgba8; sa.z_out = c->z_out;
         sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.cov_counters = c->cov_counters;
-        sa.blk_touched = c->blk_flags; sa.blk_painted = c->blk_flags + c->n_blk;
+        sa.blk_flags = c->blk_flags;
         sa.draw0 = c->draw0;
 
         sa.skip_clean = (sa.self_clean && c->skip_clean) ? 1 : 0;
@@ -993,7 +994,26 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
         c->cov_dirty = true;
         sa.ext = c->ext_table;
         const dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, (c->H + kShadeBH - 1) / kShadeBH);
-        if (c->frame_has_ext) hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(256), 0, c->stream, sa);
+        sa.trace = nullptr;
+        static const char* shade_trace = std::getenv("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
+        if (shade_trace && !c->frame_has_ext) {
+            const size_t words = (size_t)sgrid.x * sgrid.y * 4 * 4;
+            static unsigned long long* buf = nullptr;
+            static size_t buf_words = 0;
+            if (buf_words < words) {
+                (void)hipFree(buf);
+                TR_HIP(c, hipMalloc(&buf, words * sizeof(unsigned long long)));
+                buf_words = words;
+            }
+            TR_HIP(c, hipMemsetAsync(buf, 0, words * sizeof(unsigned long long), c->stream));
+            sa.trace = buf;
+            hipLaunchKernelGGL((k_shade<false, true>), sgrid, dim3(256), 0, c->stream, sa);
+            TR_HIP(c, hipGetLastError());
+            std::vector<unsigned long long> h(words);
+            TR_HIP(c, hipStreamSynchronize(c->stream));
+            TR_HIP(c, hipMemcpy(h.data(), buf, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE* f = std::fopen(shade_trace, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), words, f); std::fclose(f); }
+        } else if (c->frame_has_ext) hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(256), 0, c->stream, sa);
         else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(256), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }

@@ -509,7 +509,7 @@ struct RasterArgs {
     unsigned long long* counters;
     uint32_t* flags;
     NanTable* nan;
-    uint8_t* blk_touched;       // per shade block (32x8 pixels): 1 = a winner key was written into it
+    uint8_t* blk_touched;       // per shade block (32x8 pixels), at [2 * block]: 1 = a winner key was written into it
     int blocks_x;
     uint8_t* chunk_live;        // per 64-slot chunk of the frame: 1 = some sample may be a winner
     uint32_t live_cap;          // chunks beyond this are always treated as live
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                     const unsigned long long key = (sRecU[sx[u] * 8 + 7] & ~kRecHresMask) | (unsigned long long)jj[u];
                     if (act[u] && (!PRECHECK || key < a.wkey[pix[u]])) {
                         atomicMin(&a.wkey[pix[u]], key);
-                        a.blk_touched[blk[u]] = 1;  // the shade pass skips blocks nobody wrote a key into
+                        a.blk_touched[2u * blk[u]] = 1;  // the shade pass skips blocks nobody wrote a key into
                     }
                     rare |= nan_active && st[u] != 0;
                 }
@@ -936,11 +936,13 @@ struct ShadeArgs {
     double* rgba_f64;   // optional, 4 per pixel
     uint32_t* flags;
     unsigned long long* cov_counters;  // kCounterSlots x 8, [0] of each slot used
-    uint8_t* blk_touched;  // per 32x8 block: the winner pass wrote a key into it this frame
-    uint8_t* blk_painted;  // per block: rgba8 holds something other than the background
+    // two bytes per 32x8 block, side by side so that one scalar load brings both:
+    // [2 b] the winner pass wrote a key into the block this frame, [2 b + 1] rgba8 holds something other than the background
+    uint8_t* blk_flags;
     int skip_clean;        // blocks neither touched nor painted are left alone (RGBA8-only resolve, global raster)
     DrawDev draw0;         // copy of draws[0]
     const DrawExt* ext;    // k_shade<true>: per draw
+    unsigned long long* trace;  // k_shade<.., true> (TR_SHADE_TRACE, tools/shade_trace.py): 4 words per wave
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -978,6 +980,17 @@ __device__ __forceinline__ void sample_rgb(const uint32_t* __restrict__ img, int
     }
 }
 
+// Loads from a wave-uniform address through the scalar cache (constant address space).  The data
+// was written by an earlier kernel; the only writer in this kernel is the reader's own workgroup.
+__device__ __forceinline__ uint32_t uniform_u32(const uint32_t* p) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>((uintptr_t)p);
+}
+__device__ __forceinline__ uint32_t uniform_u16(const uint8_t* p) {  // p 2-byte aligned
+    const uintptr_t addr = (uintptr_t)p;
+    const uint32_t w = *reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(addr & ~(uintptr_t)3);
+    return (w >> ((uint32_t)(addr & 2u) * 8u)) & 0xFFFFu;
+}
+
 // Rust `v as u8`
 __device__ __forceinline__ uint32_t f64_as_u8(double v) {
     if (!(v > 0.0)) return 0u;  // NaN, negative, zero
@@ -989,8 +1002,18 @@ __device__ __forceinline__ uint32_t f64_as_u8(double v) {
 // EXT = false: the reference's shader, the tuned path of every parity test and of the benchmark.
 // EXT = true: a frame in which some draw asked for an extension shader (DrawExt); draws without one
 // still get the reference's formula, operation for operation.
-template <bool EXT>
+template <bool EXT, bool TRACE = false>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+    unsigned long long tr_t0 = 0;
+    if (TRACE) tr_t0 = wall_clock64();
+    auto trace_end = [&](uint32_t covered) {
+        if (TRACE && (threadIdx.x & 63) == 0) {
+            unsigned long long* t = a.trace + 4 * (size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6));
+            t[0] = tr_t0; t[1] = wall_clock64();
+            t[2] = covered;
+            t[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+        }
+    };
     const int x = blockIdx.x * kShadeBW + (threadIdx.x & (kShadeBW - 1));
     const int y = blockIdx.y * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
@@ -1000,13 +1023,20 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         // Nothing landed in this block: its keys are all "none".  If the previous frame left it
         // at the background colour too there is nothing to do; otherwise repaint the background.
         // (A NaN-depth winner is written outside the winner pass: no skipping in such a frame.)
-        const bool touched = a.blk_touched[blk] != 0 || (a.nan && a.nan->pix[0] != kNanEmpty);
-        const bool painted = a.blk_painted[blk] != 0;
+        // (scalar loads: a wave of an untouched block must not queue behind the vector memory traffic
+        // of the waves that shade; measured, such waves lived 1.5 us and held half of the wave slots)
+        // (both loads issued before either is needed: one round trip)
+        const uint32_t f_both = uniform_u16(a.blk_flags + 2u * blk);
+        const uint32_t f_nan = uniform_u32(a.nan ? &a.nan->pix[0] : reinterpret_cast<const uint32_t*>(a.blk_flags));
+        const uint32_t f_touched = f_both & 0xFFu, f_painted = f_both >> 8;
+        const bool touched = f_touched != 0 || (a.nan && f_nan != kNanEmpty);
+        const bool painted = f_painted != 0;
+        if (!touched && !painted) { trace_end(0xFFFFFFFFu); return; }  // (nobody writes the flags on this path)
         __syncthreads();  // every wave has read the flags before thread 0 rewrites them
         if (!touched) {
-            if (!painted) return;
             if (live) a.rgba8[pix] = 0xFF000000u;  // BLACK, helpers/mod.rs:22
-            if (threadIdx.x == 0) a.blk_painted[blk] = 0;
+            if (threadIdx.x == 0) a.blk_flags[2u * blk + 1u] = 0;
+            trace_end(0xFFFFFFFEu);
             return;
         }
     }
@@ -1031,11 +1061,11 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     {
         const int any = __syncthreads_or(has ? 1 : 0);
         if (threadIdx.x == 0) {
-            a.blk_painted[blk] = any ? 1 : 0;
-            if (a.self_clean) a.blk_touched[blk] = 0;
+            a.blk_flags[2u * blk + 1u] = any ? 1 : 0;
+            if (a.self_clean) a.blk_flags[2u * blk] = 0;
         }
     }
-    if (!live) return;
+    if (!live) { trace_end(0u); return; }
     double col[4] = {0.0, 0.0, 0.0, 255.0};  // BLACK, helpers/mod.rs:22
     double zval = -__builtin_huge_val();
     uint32_t tri = 0xFFFFFFFFu;
@@ -1156,10 +1186,12 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         double4 o = make_double4(col[0], col[1], col[2], col[3]);
         reinterpret_cast<double4*>(a.rgba_f64)[pix] = o;
     }
+    if (TRACE) trace_end((uint32_t)__popcll(__ballot(has)));
 }
 
-template __global__ void k_shade<false>(ShadeArgs);
-template __global__ void k_shade<true>(ShadeArgs);
+template __global__ void k_shade<false, false>(ShadeArgs);
+template __global__ void k_shade<true, false>(ShadeArgs);
+template __global__ void k_shade<false, true>(ShadeArgs);
 
 __global__ void k_put_ext(DrawExt e, DrawExt* table, uint32_t draw) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[draw] = e;

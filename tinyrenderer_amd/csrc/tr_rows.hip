@@ -28,7 +28,7 @@ struct RowArgs {
     uint32_t* refs;            // slot ids, grouped by bin
     uint32_t ref_cap;
     unsigned long long* wkey;  // winner key plane, row-major; only pixels that received a sample are written
-    uint8_t* blk_touched;      // per 32x8 shade block
+    uint8_t* blk_touched;      // per 32x8 shade block, at [2 * block]
     int blocks_x;
     int W, H, nseg;
     int y_lo, y_hi;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kRowThreads) void k_row_raster(RowArgs a) {
             const int x = x0 + p;
             if (k != kKeyNone && x < a.W) {
                 a.wkey[(size_t)row * (size_t)a.W + (size_t)x] = k;
-                a.blk_touched[(uint32_t)(row / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(x / kShadeBW)] = 1;
+                a.blk_touched[2u * ((uint32_t)(row / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(x / kShadeBW))] = 1;
             }
         }
         if (a.trace && lane == 0 && bi < a.trace_cap) {
