@@ -39,7 +39,7 @@ def main():
     work = (~skipped) & (cov > 0)
     print(f"{len(t)} waves traced; skipped-block waves {skipped.sum()}, waves without a covered pixel {((~skipped) & (cov == 0)).sum()}, "
           f"waves with covered pixels {work.sum()} (mean {cov[work].mean():.1f} px)")
-    print(f"launch span {e.max():.1f} us; skipped waves: last begins at {b[skipped].max():.1f} us")
+    print(f"launch span {e.max():.1f} us" + (f"; skipped waves: last begins at {b[skipped].max():.1f} us" if skipped.any() else ""))
     d = e[work] - b[work]
     print(f"covered waves: life us mean {d.mean():.2f} p10 {np.percentile(d, 10):.2f} p50 {np.median(d):.2f} p90 {np.percentile(d, 90):.2f} max {d.max():.2f}")
     print(f"   begin p1 {np.percentile(b[work], 1):.1f} p50 {np.median(b[work]):.1f} p99 {np.percentile(b[work], 99):.1f}; "
