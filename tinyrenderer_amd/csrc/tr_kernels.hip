@@ -647,7 +647,7 @@ constexpr int kChunkSlots = 64;
 template <int PASS, bool PRECHECK>
 __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     __shared__ uint4 sRec4[kChunkSlots * 4];
-    __shared__ uint32_t sPre[kChunkSlots + 1];
+    __shared__ __align__(16) uint32_t sPre[kChunkSlots + 4];  // exclusive prefix of the slots' sample counts, [64] = total
     __shared__ uint32_t sOff[PASS == 0 ? kHalfCache + 1 : 1];
     __shared__ uint32_t sEnds[2];
     const double* sRecD = reinterpret_cast<const double*>(sRec4);
@@ -769,6 +769,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         __syncthreads();
         const uint32_t total = sPre[64];
         if (a.trace && threadIdx.x == 0) tr_t1 = wall_clock64();
+        // first samples of slots 8, 16, .., 56: the same for every lane (scalar registers); a sample
+        // finds its group of 8 slots among them without touching LDS
+        const uint32_t g1 = sPre[8], g2 = sPre[16], g3 = sPre[24], g4 = sPre[32], g5 = sPre[40], g6 = sPre[48], g7 = sPre[56];
 
         // ---- sample phase, kBatch samples per thread in flight: the depth-plane loads of a batch
         // are issued together and waited for once (a wave's wait on a load also waits for the
@@ -783,11 +786,22 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                 const uint32_t k = k0 + (uint32_t)(u * kRasterThreads);
                 st[u] = 0; pix[u] = 0; jj[u] = 0; sx[u] = 0; enc[u] = 0; blk[u] = 0;
                 if (k < total) {
-                    uint32_t sidx = 0;
-#pragma unroll
-                    for (uint32_t step = 32; step; step >>= 1)
-                        if (sPre[sidx + step] <= k) sidx += step;
-                    const uint32_t j = k - sPre[sidx];
+                    // slot of sample k = the last slot whose first sample is <= k: group of 8 from the
+                    // uniform values, then the group's 8 prefix entries in two 16-byte LDS reads and a
+                    // selection tree in registers (one LDS round trip instead of six dependent ones)
+                    const bool c4 = g4 <= k;
+                    const bool c2 = (c4 ? g6 : g2) <= k;
+                    const bool c1 = (c4 ? (c2 ? g7 : g5) : (c2 ? g3 : g1)) <= k;
+                    const uint32_t grp = (c4 ? 4u : 0u) + (c2 ? 2u : 0u) + (c1 ? 1u : 0u);
+                    const uint4 ea = *reinterpret_cast<const uint4*>(&sPre[8u * grp]);
+                    const uint4 eb = *reinterpret_cast<const uint4*>(&sPre[8u * grp + 4u]);
+                    const bool d4 = eb.x <= k;
+                    const uint32_t a0 = d4 ? eb.x : ea.x, a1 = d4 ? eb.y : ea.y, a2 = d4 ? eb.z : ea.z, a3 = d4 ? eb.w : ea.w;
+                    const bool d2 = a2 <= k;
+                    const uint32_t b0 = d2 ? a2 : a0, b1 = d2 ? a3 : a1;
+                    const bool d1 = b1 <= k;
+                    const uint32_t sidx = 8u * grp + (d4 ? 4u : 0u) + (d2 ? 2u : 0u) + (d1 ? 1u : 0u);
+                    const uint32_t j = k - (d1 ? b1 : b0);
                     const double* r = sRecD + sidx * 8;
                     const double sp = (double)j * r[6];
                     const double x = r[0] + sp * r[3];
