@@ -810,9 +810,12 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                     const int ix = pixel_coord(x, a.W);
                     const int iy = pixel_coord(y, a.H);
                     const bool inb = ix >= 0 && iy >= a.y_lo && iy < a.y_hi;
-                    if (PASS == 0 && chunk * 64u + sidx >= s_count) {
-                        cnt_samples += 1;
-                        cnt_inb += inb ? 1 : 0;
+                    if (PASS == 0) {
+                        // counted per wave (a vote and a scalar population count instead of two
+                        // 64-bit adds in every lane); the totals are taken from lane 0 at the end
+                        const bool counted = chunk * 64u + sidx >= s_count;
+                        cnt_samples += (unsigned long long)__popcll(__ballot(counted));
+                        cnt_inb += (unsigned long long)__popcll(__ballot(counted && inb));
                     }
                     if (inb) {
                         const double dist = -z;
@@ -907,12 +910,12 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         }
     }
     if (PASS == 0) {
+        // cnt_samples / cnt_inb are per-wave totals already (every lane that took part in a vote holds
+        // them; lane 0 takes part in every one its wave casts); cnt_scan is per lane
+        cnt_samples = (unsigned long long)__shfl((long long)cnt_samples, 0, 64);
+        cnt_inb = (unsigned long long)__shfl((long long)cnt_inb, 0, 64);
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            cnt_samples += __shfl_down(cnt_samples, d, 64);
-            cnt_inb += __shfl_down(cnt_inb, d, 64);
-            cnt_scan += __shfl_down(cnt_scan, d, 64);
-        }
+        for (int d = 32; d > 0; d >>= 1) cnt_scan += __shfl_down(cnt_scan, d, 64);
         if (lane == 0 && (cnt_samples | cnt_scan)) {
             // one 64-byte slot per block (mod kCounterSlots): same-address atomics serialise
             unsigned long long* slot = a.counters + (size_t)(blockIdx.x % kCounterSlots) * 8;
