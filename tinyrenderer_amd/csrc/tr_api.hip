@@ -65,6 +65,10 @@ struct tr_context {
     uint32_t rec_cap = 1u << 20;     // 64 MB; slots beyond are rebuilt by every raster pass (TR_SCAN_RECORDS)
     bool rec_auto = true;            // grow with the first draw of a frame unless TR_SCAN_RECORDS pins the size
     uint8_t* chunk_live = nullptr;
+    uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
+    bool small_path = true;          // TR_SMALL_TRIS=0 disables k_small
+    uint32_t small_draw_tris = 16384; // draws with at least this many triangles use it (TR_SMALL_DRAW)
+    bool small_any = false;          // some draw since tr_clear flagged small triangles
     // row raster (mode 2)
     uint32_t* bin_cnt = nullptr;
     uint32_t* bin_off = nullptr;
@@ -180,6 +184,8 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     TriRaster* nr = nullptr;
     TriShade* ns = nullptr;
     uint32_t *ncnt = nullptr, *noff = nullptr;
+    uint8_t* nlive = nullptr;
+    TR_HIP(c, hipMalloc(&nlive, 2 * cap));
     TR_HIP(c, hipMalloc(&nr, cap * sizeof(TriRaster)));
     TR_HIP(c, hipMalloc(&ns, cap * sizeof(TriShade)));
     TR_HIP(c, hipMalloc(&ncnt, 2 * cap * sizeof(uint32_t)));
@@ -190,6 +196,7 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
         TR_HIP(c, hipMemcpyAsync(ns, c->shade, n * sizeof(TriShade), hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(ncnt, c->half_cnt, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(noff, c->half_off, (2 * n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        TR_HIP(c, hipMemcpyAsync(nlive, c->half_live, 2 * n, hipMemcpyDeviceToDevice, c->stream));
     } else if (c->half_off) {
         TR_HIP(c, hipMemcpyAsync(noff, c->half_off, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
@@ -197,7 +204,8 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     }
     TR_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt); (void)hipFree(c->half_off);
-    c->rast = nr; c->shade = ns; c->half_cnt = ncnt; c->half_off = noff;
+    (void)hipFree(c->half_live);
+    c->rast = nr; c->shade = ns; c->half_cnt = ncnt; c->half_off = noff; c->half_live = nlive;
     c->tri_cap = cap;
     size_t tiles = (2 * cap + kScanTile - 1) / kScanTile;
     if (tiles > c->tile_cap) {
@@ -307,8 +315,15 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
     if (pass == 0) {
         if (c->precheck) hipLaunchKernelGGL((k_raster<0, true>), grid, block, 0, c->stream, ra);
         else hipLaunchKernelGGL((k_raster<0, false>), grid, block, 0, c->stream, ra);
+        if (c->small_any) {
+            const dim3 sg((h_hi - h_lo + 255u) / 256u);
+            if (c->precheck) hipLaunchKernelGGL((k_small<0, true>), sg, dim3(256), 0, c->stream, ra, c->half_live);
+            else hipLaunchKernelGGL((k_small<0, false>), sg, dim3(256), 0, c->stream, ra, c->half_live);
+        }
         if (h_hi / 2u > c->counted_upto) c->counted_upto = h_hi / 2u;
     } else {
+        if (c->small_any)  // (before k_raster<1>, whose tail zeroes the other half of the per-frame state)
+            hipLaunchKernelGGL((k_small<1, false>), dim3((h_hi - h_lo + 255u) / 256u), dim3(256), 0, c->stream, ra, c->half_live);
         // measured on MI355X (4K african_head): the winner pass is faster without the filter
         // (44 vs 52 us), the depth pass with it (71 vs 93 us)
         if (c->precheck_winner) hipLaunchKernelGGL((k_raster<1, true>), grid, block, 0, c->stream, ra);
@@ -461,6 +476,8 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_SMALL_TRIS")) c->small_path = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_SMALL_DRAW")) c->small_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SCAN_RECORDS")) {
         c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -541,7 +558,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -588,6 +605,7 @@ int tr_clear(tr_context* c) {
     c->resolved = false;
     c->resolved_mask = 0;
     c->frame_has_ext = false;
+    c->small_any = false;
     return TR_OK;
 }
 
@@ -794,6 +812,10 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
         sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;  // (the row raster uses the global raster's slot sequence)
+        if (c->mode == 0 && c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
+            sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots
+            c->small_any = true;
+        }
         DrawDev& d = sa.params;
         std::memset(&d, 0, sizeof(d));
         d.tex = p->diffuse ? p->diffuse->dev : nullptr;

@@ -31,12 +31,14 @@ struct __attribute__((aligned(128))) TriRaster {
     double s0[3], s1[3], s2[3], sp[3];
     uint32_t res[2];  // resolution of half 0 / half 1 (mod.rs:363-369); 0 = no scanlines
     uint16_t tx0, ty0, tx1, ty1;  // inclusive rect of 16x16 tiles its samples can touch (tx0 > tx1: none)
-    uint32_t flags;               // kTriNonFinite: x/y of a point is NaN/inf, no range pruning
+    uint32_t flags;               // kTriNonFinite: x/y of a point is NaN/inf, no range pruning; kTriSmall
     uint32_t slot_shift;          // each scanline of this triangle occupies 1 << slot_shift slots of the
                                   // frame's slot sequence (load balance of the global raster, see k_setup)
     uint32_t pad[2];
 };
 constexpr uint32_t kTriNonFinite = 1u;
+constexpr uint32_t kTriSmall = 2u;     // both halves have at most kSmallRes + 1 scanlines: rastered by k_small, owns no slots
+constexpr uint32_t kSmallRes = 4u;
 constexpr int kTile = 16;             // screen tile edge in pixels
 constexpr double kPruneMargin = 1.0 / 64.0;  // slack (pixels) of every conservative range test
 static_assert(sizeof(TriRaster) == 128, "TriRaster must be 128 B");

@@ -137,6 +137,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
     }
     TriRaster R;
     TriShade S;
+    bool small = false;
     R.res[0] = R.res[1] = 0;
     R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0; R.slot_shift = 0;
     R.pad[0] = R.pad[1] = 0;
@@ -319,6 +320,13 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
                 }
             }
         }
+        // A triangle of a few pixels (a few scanlines of a few samples each) is cheaper as ONE thread
+        // per half that walks its samples than as slots of the frame-wide sequence: k_small takes it,
+        // and it owns no slots.  (mode bit 2: the draw uses that path.)
+        if ((a.mode & 4) && res0 && res0 <= kSmallRes && res1 <= kSmallRes && !(R.flags & kTriNonFinite)) {
+            R.flags |= kTriSmall;
+            small = true;
+        }
         a.rast[seq] = R;
         a.shade[seq] = S;
         if ((a.mode & 2) && res0) {
@@ -334,8 +342,8 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         }
     }
     if (a.mode & 1) {  // slots per half
-        a.half_cnt[2 * (size_t)seq] = res0 ? (res0 + 1u) << R.slot_shift : 0u;
-        a.half_cnt[2 * (size_t)seq + 1] = res1 ? (res1 + 1u) << R.slot_shift : 0u;
+        a.half_cnt[2 * (size_t)seq] = res0 && !small ? (res0 + 1u) << R.slot_shift : 0u;
+        a.half_cnt[2 * (size_t)seq + 1] = res1 && !small ? (res1 + 1u) << R.slot_shift : 0u;
     }
 }
 
@@ -925,6 +933,121 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         }
     }
 }
+
+// ---------------------------------------------------------------- small triangles
+// The same two passes for triangles flagged kTriSmall (k_setup), which own no slots: one thread per
+// triangle HALF walks its (res + 1) x (hres + 1) samples in the reference's order.  A high-polygon
+// mesh (BASELINE.json configs[3]: 10^7 triangles of under a pixel) puts all of a half's samples on
+// one or two pixels, so the thread merges consecutive samples of a pixel before it touches memory:
+// one depth test + atomic per pixel instead of one per sample, and no scanline records at all.
+// half_live[h] (depth pass: some sample was <= the plane when it arrived) lets the winner pass skip
+// the halves that cannot hold a winner.
+template <int PASS, bool PRECHECK>
+__global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live) {
+    const uint32_t h = a.h_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
+    bool nan_active = false;
+    if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
+    bool mine = h < a.h_hi;
+    if (mine) mine = (a.rast[h >> 1].flags & kTriSmall) != 0;
+    if (mine && PASS == 1 && a.use_live && !nan_active) mine = half_live[h] != 0;
+    if (mine) {
+        const uint32_t tri = h >> 1, half = h & 1u;
+        const TriRaster& t = a.rast[tri];
+        const uint32_t res = t.res[half];
+        const double delta = 1.0 / (double)res;
+        const bool counted = h >= a.count_h;
+        bool live = false;
+        uint32_t pend_pix = 0xFFFFFFFFu;       // depth pass: pixel whose minimum is still in registers
+        unsigned long long pend_enc = 0;       // winner pass: pend_pix = last pixel this thread wrote a key to
+        auto flush = [&]() {
+            if (PASS == 0 && pend_pix != 0xFFFFFFFFu) {
+                const unsigned long long cur = PRECHECK ? a.depth[pend_pix] : ~0ull;
+                if (!PRECHECK || pend_enc <= cur) live = true;
+                if (!PRECHECK || pend_enc < cur) atomicMin(&a.depth[pend_pix], pend_enc);
+            }
+        };
+        for (uint32_t i = 0; i <= res; ++i) {
+            const Scanline sl = make_scanline(t, half, i, delta);
+            const double inv = 1.0 / (double)sl.hres;
+            if (counted) cnt_scan += 1;
+            for (uint32_t j = 0; j <= sl.hres; ++j) {
+                const double sp = (double)j * inv;
+                const double x = sl.ax + sp * sl.dx;
+                const double y = sl.ay + sp * sl.dy;
+                const double z = sl.az + sp * sl.dz;
+                const int ix = pixel_coord(x, a.W);
+                const int iy = pixel_coord(y, a.H);
+                const bool inb = ix >= 0 && iy >= a.y_lo && iy < a.y_hi;
+                if (PASS == 0 && counted) {
+                    cnt_samples += 1;
+                    cnt_inb += inb ? 1 : 0;
+                }
+                if (!inb) continue;
+                const double dist = -z;
+                const uint32_t pix = (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+                const unsigned long long key = ((unsigned long long)tri << kKeyTriShift) | ((unsigned long long)half << kKeyHalfShift) |
+                                               ((unsigned long long)i << kKeyIShift) | (unsigned long long)j;
+                if (dist != dist) {  // NaN depth: the side table, as in k_raster
+                    if (PASS == 0) {
+                        live = true;
+                        bool placed = false;
+                        for (uint32_t s = 0; s < kNanSlots && !placed; ++s) {
+                            uint32_t old = atomicCAS(&a.nan->pix[s], kNanEmpty, pix);
+                            placed = old == kNanEmpty || old == pix;
+                        }
+                        if (!placed) atomicOr(a.flags, 1u << 5);
+                    } else if (nan_active) {
+                        for (uint32_t s = 0; s < kNanSlots; ++s)
+                            if (a.nan->pix[s] == pix) atomicMin((unsigned long long*)&a.nan->first_nan[s], key);
+                    }
+                    continue;
+                }
+                const unsigned long long enc = encode_depth(dist);
+                if (PASS == 0) {
+                    if (dist == -__builtin_huge_val()) atomicOr(a.flags, 1u << 3);
+                    if (pix == pend_pix) {
+                        pend_enc = enc < pend_enc ? enc : pend_enc;
+                    } else {
+                        flush();
+                        pend_pix = pix;
+                        pend_enc = enc;
+                    }
+                } else {
+                    if (nan_active) {
+                        for (uint32_t s = 0; s < kNanSlots; ++s)
+                            if (a.nan->pix[s] == pix) atomicMin((unsigned long long*)&a.nan->first_any[s], key);
+                    }
+                    // (samples come in key order: after a hit on a pixel, later ones on it cannot win)
+                    if (pix != pend_pix && a.depth[pix] == enc) {
+                        atomicMin(&a.wkey[pix], key);
+                        a.blk_touched[2u * ((uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW))] = 1;
+                        pend_pix = pix;
+                    }
+                }
+            }
+        }
+        flush();
+        if (PASS == 0) half_live[h] = live ? 1 : 0;
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            cnt_samples += __shfl_down(cnt_samples, d, 64);
+            cnt_inb += __shfl_down(cnt_inb, d, 64);
+            cnt_scan += __shfl_down(cnt_scan, d, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && (cnt_samples | cnt_scan)) {
+            unsigned long long* slot = a.counters + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8;
+            atomicAdd(&slot[0], cnt_samples);
+            atomicAdd(&slot[1], cnt_inb);
+            atomicAdd(&slot[2], cnt_scan);
+        }
+    }
+}
+template __global__ void k_small<0, true>(RasterArgs, uint8_t*);
+template __global__ void k_small<0, false>(RasterArgs, uint8_t*);
+template __global__ void k_small<1, false>(RasterArgs, uint8_t*);
 
 template __global__ void k_setup<false>(SetupArgs);
 template __global__ void k_setup<true>(SetupArgs);
