@@ -456,6 +456,63 @@ def test_row_raster_grows_its_buffers(oracle, monkeypatch):
             monkeypatch.delenv(k)
 
 
+def test_small_triangle_path(oracle, monkeypatch):
+    """k_small (one thread per triangle half, taken by triangles of at most 9 scanlines per half in
+    draws of 65 536 triangles or more): forced onto every draw here.  Whole frames, counters, bands,
+    a frame extended after a resolve, NaN depths and a mesh that mixes small and large triangles."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader, ModelRendererState, clear_screen, render_mesh_component
+    from tinyrenderer_amd import _ffi
+
+    monkeypatch.setenv("TR_SMALL_DRAW", "1")
+    for W, Hh in ((64, 48), (200, 160)):  # the head's 2492 triangles: all small / most small
+        draws = _head_scene(W, Hh, with_eye=True)
+        o = SU.oracle_render(oracle, W, Hh, draws)
+        g = SU.gpu_render(W, Hh, draws, mode=0)
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], k
+        top = SU.gpu_render(W, Hh, draws, mode=0, band=(0, 32))
+        assert np.array_equal(top["key"][:, :32], o["key"][:, :32]) and (top["key"][:, 32:] == np.uint64(2**64 - 1)).all()
+    # a frame extended after an RGBA8-only resolve (the depth pass of the whole frame is redone)
+    W, Hh = 160, 120
+    draws = _head_scene(W, Hh, with_eye=True)
+    o2 = SU.oracle_render(oracle, W, Hh, draws)
+    st = ModelRendererState(W, Hh, raster_mode=0)
+    try:
+        clear_screen(st)
+        render_mesh_component(st, *draws[0])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        render_mesh_component(st, *draws[1])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        assert np.array_equal(st.present(), o2["present"])
+        assert np.array_equal(st.winner_keys(), o2["key"])
+        assert st.counters()["samples"] == o2["counters"]["samples"]
+    finally:
+        st.close()
+    # NaN depths from a degenerate small triangle, before and after a triangle that covers the pixel
+    N = H.NONE_INDEX
+    degenerate = H.Object([[-0.5, 0.25, 0.0], [0.5, 0.25, 0.0], [0.0, 0.25, 0.0]],
+                          [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)), [[0, 0, N, 1, 1, N, 2, 2, N]])
+    big = H.Object([[-1, -1, 0.5], [1, -1, 0.5], [-1, 1, 0.5]], np.zeros((0, 3)), np.zeros((0, 3)),
+                   [[0, N, N, 1, N, N, 2, N, N]])
+    d, b = _synthetic_component(degenerate), _synthetic_component(big)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    for order in ((d, b), (b, d)):
+        for W, Hh in ((8, 8), (16, 16)):  # at 8x8 both triangles are small
+            frame = [(mc, sh) for mc in order]
+            SU.assert_parity(SU.oracle_render(oracle, W, Hh, frame), SU.gpu_render(W, Hh, frame, mode=0))
+    # random triangles of every size in one mesh (tiny ones, slivers, huge ones, some off screen)
+    rng = np.random.default_rng(77)
+    for n_tris, W, Hh in ((300, 96, 80), (1500, 64, 64), (60, 24, 16)):
+        draws = _random_scene(rng, n_tris, W, Hh, spread=1.1)
+        o = SU.oracle_render(oracle, W, Hh, draws)
+        g = SU.gpu_render(W, Hh, draws, mode=0)
+        SU.assert_parity(o, g)
+        assert g["counters"]["samples"] == o["counters"]["samples"]
+
+
 def test_device_arithmetic_shortcuts_are_exact():
     """tr_selftest_arithmetic: x/255 by fmas and the rounding shortcut against `/` and round() on
     the device, 6e8 operands each."""

@@ -67,7 +67,8 @@ struct tr_context {
     uint8_t* chunk_live = nullptr;
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
     bool small_path = true;          // TR_SMALL_TRIS=0 disables k_small
-    uint32_t small_draw_tris = 16384; // draws with at least this many triangles use it (TR_SMALL_DRAW)
+    uint32_t small_draw_tris = 65536; // draws with at least this many triangles use it (TR_SMALL_DRAW)
+    uint32_t small_res = kSmallRes;  // TR_SMALL_RES
     bool small_any = false;          // some draw since tr_clear flagged small triangles
     // row raster (mode 2)
     uint32_t* bin_cnt = nullptr;
@@ -477,6 +478,7 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SMALL_TRIS")) c->small_path = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_SMALL_RES")) c->small_res = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SMALL_DRAW")) c->small_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SCAN_RECORDS")) {
@@ -811,9 +813,11 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.nmat = nmat;
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+        sa.small_res = 0;
         sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;  // (the row raster uses the global raster's slot sequence)
         if (c->mode == 0 && c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
             sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots
+            sa.small_res = c->small_res;
             c->small_any = true;
         }
         DrawDev& d = sa.params;

@@ -37,8 +37,8 @@ struct __attribute__((aligned(128))) TriRaster {
     uint32_t pad[2];
 };
 constexpr uint32_t kTriNonFinite = 1u;
-constexpr uint32_t kTriSmall = 2u;     // both halves have at most kSmallRes + 1 scanlines: rastered by k_small, owns no slots
-constexpr uint32_t kSmallRes = 4u;
+constexpr uint32_t kTriSmall = 2u;     // both halves have at most small_res + 1 scanlines (kSmallRes by default): rastered by k_small, owns no slots
+constexpr uint32_t kSmallRes = 8u;
 constexpr int kTile = 16;             // screen tile edge in pixels
 constexpr double kPruneMargin = 1.0 / 64.0;  // slack (pixels) of every conservative range test
 static_assert(sizeof(TriRaster) == 128, "TriRaster must be 128 B");

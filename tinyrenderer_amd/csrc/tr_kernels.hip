@@ -55,7 +55,8 @@ struct SetupArgs {
     uint32_t* tile_cnt;    // triangles per tile (tile raster only)
     int tiles_x, tiles_y;
     int y_lo, y_hi;        // band of pixel rows owned by this context
-    int mode;              // bit0: fill half_cnt, bit1: count tiles
+    int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small)
+    uint32_t small_res;    // a triangle is small if neither half has more than small_res + 1 scanlines
     uint32_t* flags;
     DrawDev params;
     DrawDev* draw_table;
@@ -323,7 +324,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         // A triangle of a few pixels (a few scanlines of a few samples each) is cheaper as ONE thread
         // per half that walks its samples than as slots of the frame-wide sequence: k_small takes it,
         // and it owns no slots.  (mode bit 2: the draw uses that path.)
-        if ((a.mode & 4) && res0 && res0 <= kSmallRes && res1 <= kSmallRes && !(R.flags & kTriNonFinite)) {
+        if ((a.mode & 4) && res0 && res0 <= a.small_res && res1 <= a.small_res && !(R.flags & kTriNonFinite)) {
             R.flags |= kTriSmall;
             small = true;
         }
