@@ -81,3 +81,27 @@ def test_world2_gloo_views_and_bands(tmp_path):
     assert np.array_equal(got["frames"], want)
     assert np.array_equal(got["full"], want[0])
     assert (want != np.int32(-16777216)).any()  # something other than the clear colour was drawn
+
+
+def test_balanced_bands_cover_the_frame_and_follow_the_weights():
+    """sharding.balanced_bands: contiguous bands of whole tile rows, none empty while rows remain,
+    weights about equal."""
+    import random
+
+    from tinyrenderer_amd import sharding as S
+
+    rnd = random.Random(5)
+    for world in (1, 2, 3, 8):
+        for n in (1, 3, 8, 17, 270):
+            w = [rnd.random() * 10 for _ in range(n)]
+            height = n * 16 - 5
+            b = S.balanced_bands(w, world, height=height)
+            assert len(b) == world and b[0][0] == 0 and b[-1][1] == height
+            assert all(x[1] == y[0] for x, y in zip(b[:-1], b[1:])) and all(x[0] <= x[1] for x in b)
+            if n >= world:
+                assert all(x[0] < x[1] for x in b)
+    w = [1] * 10 + [10] * 10 + [1] * 10  # the middle third carries 10/12 of the weight
+    bands = S.balanced_bands(w, 4)
+    per = [sum(w[lo // 16: hi // 16]) for lo, hi in bands]
+    assert max(per) <= 1.35 * sum(w) / 4, per
+    assert S.balanced_bands([1.0] * 8, 4) == [S.band_rows(128, r, 4) for r in range(4)]

@@ -65,6 +65,7 @@ struct tr_context {
     uint32_t rec_cap = 1u << 20;     // 64 MB; slots beyond are rebuilt by every raster pass (TR_SCAN_RECORDS)
     bool rec_auto = true;            // grow with the first draw of a frame unless TR_SCAN_RECORDS pins the size
     uint8_t* chunk_live = nullptr;
+    uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
     bool small_path = true;          // TR_SMALL_TRIS=0 disables k_small
     uint32_t small_draw_tris = 65536; // draws with at least this many triangles use it (TR_SMALL_DRAW)
@@ -185,8 +186,10 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     TriRaster* nr = nullptr;
     TriShade* ns = nullptr;
     uint32_t *ncnt = nullptr, *noff = nullptr;
-    uint8_t* nlive = nullptr;
+    uint8_t *nlive = nullptr, *nsmall = nullptr;
     TR_HIP(c, hipMalloc(&nlive, 2 * cap));
+    TR_HIP(c, hipMalloc(&nsmall, cap));
+    TR_HIP(c, hipMemsetAsync(nsmall, 0, cap, c->stream));
     TR_HIP(c, hipMalloc(&nr, cap * sizeof(TriRaster)));
     TR_HIP(c, hipMalloc(&ns, cap * sizeof(TriShade)));
     TR_HIP(c, hipMalloc(&ncnt, 2 * cap * sizeof(uint32_t)));
@@ -198,6 +201,7 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
         TR_HIP(c, hipMemcpyAsync(ncnt, c->half_cnt, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(noff, c->half_off, (2 * n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(nlive, c->half_live, 2 * n, hipMemcpyDeviceToDevice, c->stream));
+        TR_HIP(c, hipMemcpyAsync(nsmall, c->small_flag, n, hipMemcpyDeviceToDevice, c->stream));
     } else if (c->half_off) {
         TR_HIP(c, hipMemcpyAsync(noff, c->half_off, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
@@ -205,8 +209,8 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     }
     TR_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt); (void)hipFree(c->half_off);
-    (void)hipFree(c->half_live);
-    c->rast = nr; c->shade = ns; c->half_cnt = ncnt; c->half_off = noff; c->half_live = nlive;
+    (void)hipFree(c->half_live); (void)hipFree(c->small_flag);
+    c->rast = nr; c->shade = ns; c->half_cnt = ncnt; c->half_off = noff; c->half_live = nlive; c->small_flag = nsmall;
     c->tri_cap = cap;
     size_t tiles = (2 * cap + kScanTile - 1) / kScanTile;
     if (tiles > c->tile_cap) {
@@ -249,6 +253,7 @@ constexpr uint32_t kChunkLiveCap = 1u << 20;  // 64 M slots per frame get dead-c
 void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_hi) {
     ra.half_off = c->half_off;
     ra.rast = c->rast;
+    ra.small_flag = c->small_flag;
     ra.rec = c->rec;
     ra.rec_cap = c->rec_cap;
     ra.depth = c->depth;
@@ -560,7 +565,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -814,6 +819,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
         sa.small_res = 0;
+        sa.small_flag = c->small_flag;
         sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;  // (the row raster uses the global raster's slot sequence)
         if (c->mode == 0 && c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
             sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots

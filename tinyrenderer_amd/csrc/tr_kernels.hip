@@ -57,6 +57,7 @@ struct SetupArgs {
     int y_lo, y_hi;        // band of pixel rows owned by this context
     int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small)
     uint32_t small_res;    // a triangle is small if neither half has more than small_res + 1 scanlines
+    uint8_t* small_flag;   // per triangle: 1 = flagged kTriSmall (what k_small reads)
     uint32_t* flags;
     DrawDev params;
     DrawDev* draw_table;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
     R.res[0] = R.res[1] = 0;
     R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0; R.slot_shift = 0;
     R.pad[0] = R.pad[1] = 0;
-    if (cull) a.rast[seq] = R;  // the binning pass reads res / rect of every triangle
+    if (cull && (a.mode & 2)) a.rast[seq] = R;  // (only the tile raster's binning pass reads the record of every triangle)
     if (!cull) {
         // mod.rs:320-327 viewport transform; w of the product is 1 unless inputs are non-finite.
         double vx[3], vy[3], vz[3];
@@ -154,6 +155,18 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
             vy[c] = g[1] / g[3];
             vz[c] = g[2] / g[3];
         }
+        // A context that owns a band of rows (multi-GPU, tr_set_band): a triangle none of whose samples
+        // can land in the band (every sample lies in the hull of the corners up to a few ulp and lands
+        // in row round(y)) is dropped here, before any record is built or written.
+        bool out_of_band = false;
+        if (a.y_lo > 0 || a.y_hi < a.H) {
+            const double ymin = fmin(fmin(vy[0], vy[1]), vy[2]), ymax = fmax(fmax(vy[0], vy[1]), vy[2]);
+            const bool finite = fabs(vy[0]) < __builtin_huge_val() && fabs(vy[1]) < __builtin_huge_val() && fabs(vy[2]) < __builtin_huge_val();
+            out_of_band = finite && (ceil(ymin - kPruneMargin - 0.5) > (double)(a.y_hi - 1) || floor(ymax + kPruneMargin + 0.5) < (double)a.y_lo);
+        }
+        if (out_of_band) {
+            if (a.mode & 2) a.rast[seq] = R;
+        } else {
         // mod.rs:331 stable insertion sort by y descending, NaN compares Equal.
         int o[3] = {0, 1, 2};
         auto is_less = [&](int p, int q) { return vy[q] < vy[p]; };
@@ -341,7 +354,9 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
                     for (int tx = R.tx0; tx <= R.tx1; ++tx) atomicAdd(&a.tile_cnt[ty * a.tiles_x + tx], 1u);
             }
         }
+        }  // !out_of_band
     }
+    if (a.small_flag) a.small_flag[seq] = small ? 1 : 0;  // (every draw writes it: k_small may sweep draws that do not use the path)
     if (a.mode & 1) {  // slots per half
         a.half_cnt[2 * (size_t)seq] = res0 && !small ? (res0 + 1u) << R.slot_shift : 0u;
         a.half_cnt[2 * (size_t)seq + 1] = res1 && !small ? (res1 + 1u) << R.slot_shift : 0u;
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_small(const uint32_t* __r
 struct RasterArgs {
     const uint32_t* half_off;   // exclusive prefix of slots per half (+ total at the end)
     const TriRaster* rast;
+    const uint8_t* small_flag;  // k_small: per triangle, 1 = its samples are this kernel's
     ScanRec* rec;               // records of slots [0, rec_cap); slots beyond are rebuilt on the fly
     uint32_t rec_cap;
     unsigned long long* depth;  // encoded min depth per pixel, row-major
@@ -950,7 +966,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
     bool nan_active = false;
     if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
     bool mine = h < a.h_hi;
-    if (mine) mine = (a.rast[h >> 1].flags & kTriSmall) != 0;
+    if (mine) mine = a.small_flag[h >> 1] != 0;  // (a byte per triangle: the other triangles' records are not touched)
     if (mine && PASS == 1 && a.use_live && !nan_active) mine = half_live[h] != 0;
     if (mine) {
         const uint32_t tri = h >> 1, half = h & 1u;

@@ -27,6 +27,30 @@ def band_rows(height, rank, world, tile=TILE):
     return min(lo * tile, height), min(hi * tile, height)
 
 
+def balanced_bands(tile_row_weights, world, tile=TILE, height=None):
+    """Bands of whole tile rows with about equal WEIGHT each ("balanced by binned-sample
+    count, not by area"): `tile_row_weights[k]` is the cost of tile row k, e.g. the covered pixels or
+    fragments the previous frame had there plus a constant for the per-row overhead.  Returns a list
+    of `world` bands [(y_lo, y_hi)], contiguous and covering the frame; every rank computes the same
+    list from the same weights."""
+    w = [float(x) for x in tile_row_weights]
+    n = len(w)
+    height = n * tile if height is None else height
+    prefix = [0.0]
+    for x in w:
+        prefix.append(prefix[-1] + x)
+    cuts = [0]
+    for r in range(1, world):
+        target = prefix[-1] * r / world
+        if n >= world:  # every rank gets at least one tile row
+            lo_k, hi_k = cuts[-1] + 1, n - (world - r)
+        else:
+            lo_k, hi_k = cuts[-1], n
+        cuts.append(min(range(lo_k, hi_k + 1), key=lambda k: (abs(prefix[k] - target), k)))
+    cuts.append(n)
+    return [(min(a * tile, height), min(b * tile, height)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
 def gather_frames(local, n_total, dst=0):
     """Gather per-rank blocks of finished frames (n_local, H, W) uint8/int32 onto `dst` in view
     order.  Returns the (n_total, H, W) tensor on dst, None elsewhere."""
@@ -48,14 +72,15 @@ def gather_frames(local, n_total, dst=0):
     return torch.cat(parts, dim=0)
 
 
-def gather_bands(local_band, height, dst=0, tile=TILE):
+def gather_bands(local_band, height, dst=0, tile=TILE, spans=None):
     """Gather per-rank bands (rows [y_lo, y_hi) of one frame, shape (rows, W[, C])) onto `dst`
-    and stack them into the (height, W[, C]) frame."""
+    and stack them into the (height, W[, C]) frame.  `spans`: the bands of all ranks if they are
+    not the equal ones of band_rows (balanced_bands)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return local_band
-    spans = [band_rows(height, r, world, tile) for r in range(world)]
+    spans = [band_rows(height, r, world, tile) for r in range(world)] if spans is None else list(spans)
     max_rows = max(hi - lo for lo, hi in spans)
     pad = torch.zeros((max_rows,) + tuple(local_band.shape[1:]), dtype=local_band.dtype, device=local_band.device)
     pad[: local_band.shape[0]] = local_band
