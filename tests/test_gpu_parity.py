@@ -527,3 +527,47 @@ def test_device_arithmetic_shortcuts_are_exact():
         assert rc == 0
         assert out[3] >= 200_000_000
         assert list(out[:3]) == [0, 0, 0], list(out)
+
+
+def test_context_lifecycle_leaves_no_device_memory_behind(oracle):
+    """Contexts of several sizes created, used (every raster mode, extension shaders, a shadow map,
+    late plane requests) and destroyed: the device's free memory comes back, results stay right."""
+    import torch
+
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import (ModelRendererState, ShadeExt, ShadowMap, clear_screen,
+                                                 render_mesh_component)
+
+    def cycle(W, Hh, mode):
+        draws = _head_scene(W, Hh, with_eye=True)
+        st = ModelRendererState(W, Hh, raster_mode=mode)
+        clear_screen(st)
+        for d in draws:
+            render_mesh_component(st, *d)
+        st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z)
+        sm = ShadowMap(st)
+        clear_screen(st)
+        render_mesh_component(st, draws[0][0], draws[0][1], ShadeExt(model=_ffi.TR_SHADE_PHONG, shadow=sm, shadow_dim=0.5))
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        st.present()
+        clear_screen(st)
+        for d in draws:
+            render_mesh_component(st, *d)
+        out = (st.present().copy(), st.winner_keys().copy())
+        sm.close()
+        st.close()
+        return out
+
+    ref = cycle(96, 64, 0)
+    o = SU.oracle_render(oracle, 96, 64, _head_scene(96, 64, with_eye=True))
+    assert np.array_equal(ref[0], o["present"]) and np.array_equal(ref[1], o["key"])
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(12):
+        W, Hh = (96, 64) if k % 3 == 0 else ((640, 360) if k % 3 == 1 else (33, 1000))
+        got = cycle(W, Hh, k % 3)
+        if (W, Hh) == (96, 64):
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned"
