@@ -975,13 +975,16 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
         const double delta = 1.0 / (double)res;
         const bool counted = h >= a.count_h;
         bool live = false;
-        uint32_t pend_pix = 0xFFFFFFFFu;       // depth pass: pixel whose minimum is still in registers
-        unsigned long long pend_enc = 0;       // winner pass: pend_pix = last pixel this thread wrote a key to
-        auto flush = [&]() {
-            if (PASS == 0 && pend_pix != 0xFFFFFFFFu) {
-                const unsigned long long cur = PRECHECK ? a.depth[pend_pix] : ~0ull;
-                if (!PRECHECK || pend_enc <= cur) live = true;
-                if (!PRECHECK || pend_enc < cur) atomicMin(&a.depth[pend_pix], pend_enc);
+        // depth pass: the minima of the last two pixels the half touched are still in registers (a
+        // half of under a pixel alternates between two pixels from one scanline to the next);
+        // winner pass: the last two pixels this thread wrote a key to
+        uint32_t p0 = 0xFFFFFFFFu, p1 = 0xFFFFFFFFu;
+        unsigned long long e0 = 0, e1 = 0;
+        auto flush = [&](uint32_t pp, unsigned long long ee) {
+            if (PASS == 0 && pp != 0xFFFFFFFFu) {
+                const unsigned long long cur = PRECHECK ? a.depth[pp] : ~0ull;
+                if (!PRECHECK || ee <= cur) live = true;
+                if (!PRECHECK || ee < cur) atomicMin(&a.depth[pp], ee);
             }
         };
         for (uint32_t i = 0; i <= res; ++i) {
@@ -1023,12 +1026,14 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                 const unsigned long long enc = encode_depth(dist);
                 if (PASS == 0) {
                     if (dist == -__builtin_huge_val()) atomicOr(a.flags, 1u << 3);
-                    if (pix == pend_pix) {
-                        pend_enc = enc < pend_enc ? enc : pend_enc;
-                    } else {
-                        flush();
-                        pend_pix = pix;
-                        pend_enc = enc;
+                    if (pix == p1) {
+                        e1 = enc < e1 ? enc : e1;
+                    } else if (pix == p0) {
+                        e0 = enc < e0 ? enc : e0;
+                    } else {  // the older of the two goes to memory
+                        flush(p0, e0);
+                        p0 = p1; e0 = e1;
+                        p1 = pix; e1 = enc;
                     }
                 } else {
                     if (nan_active) {
@@ -1036,15 +1041,17 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                             if (a.nan->pix[s] == pix) atomicMin((unsigned long long*)&a.nan->first_any[s], key);
                     }
                     // (samples come in key order: after a hit on a pixel, later ones on it cannot win)
-                    if (pix != pend_pix && a.depth[pix] == enc) {
+                    if (pix != p0 && pix != p1 && a.depth[pix] == enc) {
                         atomicMin(&a.wkey[pix], key);
                         a.blk_touched[2u * ((uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW))] = 1;
-                        pend_pix = pix;
+                        p0 = p1;
+                        p1 = pix;
                     }
                 }
             }
         }
-        flush();
+        flush(p0, e0);
+        flush(p1, e1);
         if (PASS == 0) half_live[h] = live ? 1 : 0;
     }
     if (PASS == 0) {
