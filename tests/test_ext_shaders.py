@@ -105,12 +105,13 @@ def test_gpu_ext_models_match_cpu_statement(model):
     mc, sh, light_sh = _scene("diablo")
     spec = scenes.load_specular("diablo") if model == _ffi.TR_SHADE_PHONG else None
     draws = [(mc, sh, ShadeExt(model=model, specular_map=spec, specular_strength=0.6))]
-    g = SU.gpu_render(W, H, draws)
     o = SU.oracle_render(oracle_ffi, W, H, draws)
-    r = SU.assert_parity(o, g, color_lsb=1)
-    assert r["covered"] > 3000
-    if model == _ffi.TR_SHADE_GOURAUD:  # no pow(): the same operations in the same order
-        assert r["f64_colour_mismatches"] == 0
+    for mode in (_ffi.TR_RASTER_GLOBAL, _ffi.TR_RASTER_TILE, _ffi.TR_RASTER_ROWS):  # the shade pass is shared
+        g = SU.gpu_render(W, H, draws, mode=mode)
+        r = SU.assert_parity(o, g, color_lsb=1)
+        assert r["covered"] > 3000
+        if model == _ffi.TR_SHADE_GOURAUD:  # no pow(): the same operations in the same order
+            assert r["f64_colour_mismatches"] == 0
 
 
 @pytest.mark.gpu
