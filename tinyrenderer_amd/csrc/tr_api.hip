@@ -320,8 +320,14 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
         c->other_state_clean = true;
     }
     if (pass == 0) {
-        if (c->precheck) hipLaunchKernelGGL((k_raster<0, true>), grid, block, 0, c->stream, ra);
-        else hipLaunchKernelGGL((k_raster<0, false>), grid, block, 0, c->stream, ra);
+        const bool dbg = ra.debug != 0 || ra.trace != nullptr;
+        if (dbg) {
+            if (c->precheck) hipLaunchKernelGGL((k_raster<0, true, true>), grid, block, 0, c->stream, ra);
+            else hipLaunchKernelGGL((k_raster<0, false, true>), grid, block, 0, c->stream, ra);
+        } else {
+            if (c->precheck) hipLaunchKernelGGL((k_raster<0, true, false>), grid, block, 0, c->stream, ra);
+            else hipLaunchKernelGGL((k_raster<0, false, false>), grid, block, 0, c->stream, ra);
+        }
         if (c->small_any) {
             const dim3 sg((h_hi - h_lo + 255u) / 256u);
             if (c->precheck) hipLaunchKernelGGL((k_small<0, true>), sg, dim3(256), 0, c->stream, ra, c->half_live);
@@ -333,8 +339,14 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
             hipLaunchKernelGGL((k_small<1, false>), dim3((h_hi - h_lo + 255u) / 256u), dim3(256), 0, c->stream, ra, c->half_live);
         // measured on MI355X (4K african_head): the winner pass is faster without the filter
         // (44 vs 52 us), the depth pass with it (71 vs 93 us)
-        if (c->precheck_winner) hipLaunchKernelGGL((k_raster<1, true>), grid, block, 0, c->stream, ra);
-        else hipLaunchKernelGGL((k_raster<1, false>), grid, block, 0, c->stream, ra);
+        const bool dbg = ra.debug != 0 || ra.trace != nullptr;
+        if (dbg) {
+            if (c->precheck_winner) hipLaunchKernelGGL((k_raster<1, true, true>), grid, block, 0, c->stream, ra);
+            else hipLaunchKernelGGL((k_raster<1, false, true>), grid, block, 0, c->stream, ra);
+        } else {
+            if (c->precheck_winner) hipLaunchKernelGGL((k_raster<1, true, false>), grid, block, 0, c->stream, ra);
+            else hipLaunchKernelGGL((k_raster<1, false, false>), grid, block, 0, c->stream, ra);
+        }
     }
     TR_HIP(c, hipGetLastError());
     return TR_OK;

@@ -669,8 +669,11 @@ constexpr int kChunkSlots = 64;
 // 16-byte load per thread; wave 0 scans the sample counts; then lanes own SAMPLES: consecutive
 // lanes take consecutive samples of a scanline, i.e. consecutive pixels of a row, so the
 // depth / winner atomics of one wave-instruction fall into contiguous 8-byte slots.
-template <int PASS, bool PRECHECK>
+template <int PASS, bool PRECHECK, bool DBG = false>
 __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
+    // (timing experiments and the per-chunk timeline live in the DBG instantiations only)
+    const int dbg_mode = DBG ? a.debug : 0;
+    unsigned long long* const dbg_trace = DBG ? a.trace : nullptr;
     __shared__ uint4 sRec4[kChunkSlots * 4];
     __shared__ __align__(16) uint32_t sPre[kChunkSlots + 4];  // exclusive prefix of the slots' sample counts, [64] = total
     __shared__ uint32_t sOff[PASS == 0 ? kHalfCache + 1 : 1];
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         }
         bool any_live = false;
         unsigned long long tr_t0 = 0, tr_t1 = 0;
-        if (a.trace && threadIdx.x == 0) tr_t0 = wall_clock64();
+        if (dbg_trace && threadIdx.x == 0) tr_t0 = wall_clock64();
         // ---- record phase.  Depth pass: build the chunk's 64 records (two waves locate the halves
         // of its first and last slot with 64 probes per round, the prefix entries between them go
         // to LDS, 64 lanes finish their search there), keep them in LDS and store them for the
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         }
         __syncthreads();
         const uint32_t total = sPre[64];
-        if (a.trace && threadIdx.x == 0) tr_t1 = wall_clock64();
+        if (dbg_trace && threadIdx.x == 0) tr_t1 = wall_clock64();
         // first samples of slots 8, 16, .., 56: the same for every lane (scalar registers); a sample
         // finds its group of 8 slots among them without touching LDS
         const uint32_t g1 = sPre[8], g2 = sPre[16], g3 = sPre[24], g4 = sPre[32], g5 = sPre[40], g6 = sPre[48], g7 = sPre[56];
@@ -858,7 +861,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                 }
             }
             unsigned long long cur[kBatch];
-            const bool want_load = (PASS == 1 || PRECHECK) && a.debug != 2;
+            const bool want_load = (PASS == 1 || PRECHECK) && dbg_mode != 2;
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)  // (lanes with nothing to do read pixel 0: no branch around the load)
                 cur[u] = want_load ? a.depth[st[u] == 1 ? pix[u] : 0u] : 0ull;
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
                 if (PASS == 0) {
-                    act[u] = st[u] == 1 && (!PRECHECK || enc[u] < cur[u]) && a.debug == 0;
+                    act[u] = st[u] == 1 && (!PRECHECK || enc[u] < cur[u]) && dbg_mode == 0;
                     any_live |= st[u] == 2 || (st[u] == 1 && (!PRECHECK || enc[u] <= cur[u]));
                 } else {
                     act[u] = st[u] == 1 && cur[u] == enc[u];
@@ -921,8 +924,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         }
         // (also the barrier before the next chunk rewrites LDS)
         const int live = __syncthreads_or(any_live ? 1 : 0);
-        if (a.trace && threadIdx.x == 0 && chunk - c_lo < a.trace_cap) {
-            unsigned long long* t = a.trace + 4 * (size_t)(chunk - c_lo);
+        if (dbg_trace && threadIdx.x == 0 && chunk - c_lo < a.trace_cap) {
+            unsigned long long* t = dbg_trace + 4 * (size_t)(chunk - c_lo);
             t[0] = tr_t0; t[1] = tr_t1; t[2] = wall_clock64();
             t[3] = (unsigned long long)total | ((unsigned long long)blockIdx.x << 32);
         }
@@ -1075,10 +1078,14 @@ template __global__ void k_small<1, false>(RasterArgs, uint8_t*);
 
 template __global__ void k_setup<false>(SetupArgs);
 template __global__ void k_setup<true>(SetupArgs);
-template __global__ void k_raster<0, true>(RasterArgs);
-template __global__ void k_raster<1, true>(RasterArgs);
-template __global__ void k_raster<0, false>(RasterArgs);
-template __global__ void k_raster<1, false>(RasterArgs);
+template __global__ void k_raster<0, true, false>(RasterArgs);
+template __global__ void k_raster<1, true, false>(RasterArgs);
+template __global__ void k_raster<0, false, false>(RasterArgs);
+template __global__ void k_raster<1, false, false>(RasterArgs);
+template __global__ void k_raster<0, true, true>(RasterArgs);
+template __global__ void k_raster<1, true, true>(RasterArgs);
+template __global__ void k_raster<0, false, true>(RasterArgs);
+template __global__ void k_raster<1, false, true>(RasterArgs);
 
 // ================================================================ (4) shade
 struct ShadeArgs {
