@@ -682,8 +682,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     const unsigned long long* sRecU = reinterpret_cast<const unsigned long long*>(sRec4);
 
     // samples a thread keeps in flight: measured on MI355X at 4K, the depth pass (bound by the
-    // atomic rate) is fastest with 1 (58 us; 63 with 2, 68 with 4), the winner pass with 4 (30 vs 31.4)
-    constexpr int kBatch = PASS == 0 ? 1 : 4;
+    // atomic rate) is fastest with 1 (58 us; 63 with 2, 68 with 4), the winner pass with 3 (72 VGPRs: 30.1 us;
+    // 2: 30.7, 4 at 82 VGPRs: 31.2)
+    constexpr int kBatch = PASS == 0 ? 1 : 3;
     const int lane = threadIdx.x & 63;
     const bool wave0 = threadIdx.x < 64;
     const uint32_t s_begin = a.half_off[a.h_lo];
@@ -806,13 +807,13 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         // atomics it issued before it, so one sample at a time costs a full memory round trip
         // plus an atomic round trip per sample)
         for (uint32_t k0 = threadIdx.x; k0 < total; k0 += (uint32_t)(kRasterThreads * kBatch)) {
-            uint32_t pix[kBatch], jj[kBatch], sx[kBatch], blk[kBatch];
+            uint32_t pix[kBatch], meta[kBatch], blk[kBatch];  // meta = slot in chunk << 18 | j
             unsigned long long enc[kBatch];
             int st[kBatch];  // 0: nothing to do, 1: finite depth, 2: NaN depth
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
                 const uint32_t k = k0 + (uint32_t)(u * kRasterThreads);
-                st[u] = 0; pix[u] = 0; jj[u] = 0; sx[u] = 0; enc[u] = 0; blk[u] = 0;
+                st[u] = 0; pix[u] = 0; meta[u] = 0; enc[u] = 0; blk[u] = 0;
                 if (k < total) {
                     // slot of sample k = the last slot whose first sample is <= k: group of 8 from the
                     // uniform values, then the group's 8 prefix entries in two 16-byte LDS reads and a
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                     if (inb) {
                         const double dist = -z;
                         pix[u] = (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
-                        jj[u] = j; sx[u] = sidx;
+                        meta[u] = (sidx << 18) | j;
                         if (PASS == 1) blk[u] = (uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW);
                         if (dist != dist) {
                             st[u] = 2;
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                     if (act[u]) atomicMin(&a.depth[pix[u]], enc[u]);
                     rare |= st[u] == 2;
                 } else {
-                    const unsigned long long key = (sRecU[sx[u] * 8 + 7] & ~kRecHresMask) | (unsigned long long)jj[u];
+                    const unsigned long long key = (sRecU[(meta[u] >> 18) * 8 + 7] & ~kRecHresMask) | (unsigned long long)(meta[u] & (uint32_t)kRecHresMask);
                     if (act[u] && (!PRECHECK || key < a.wkey[pix[u]])) {
                         atomicMin(&a.wkey[pix[u]], key);
                         a.blk_touched[2u * blk[u]] = 1;  // the shade pass skips blocks nobody wrote a key into
@@ -909,8 +910,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                         }
                         if (!placed) atomicOr(a.flags, 1u << 5);
                     } else {
-                        const uint32_t su = pick(sx);
-                        const uint32_t ju = pick(jj);
+                        const uint32_t mu = pick(meta);
+                        const uint32_t su = mu >> 18, ju = mu & (uint32_t)kRecHresMask;
                         const unsigned long long key = (sRecU[su * 8 + 7] & ~kRecHresMask) | (unsigned long long)ju;
                         for (uint32_t s = 0; s < kNanSlots; ++s) {
                             if (a.nan->pix[s] == pu) {
