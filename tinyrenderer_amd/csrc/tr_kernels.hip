@@ -692,7 +692,21 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     const uint32_t s_count = PASS == 0 ? a.half_off[a.count_h > a.h_lo ? a.count_h : a.h_lo] : 0u;
     const uint32_t c_lo = s_begin / 64u;
     const uint32_t c_hi = (uint32_t)(((unsigned long long)s_end + 63ull) / 64ull);
-    unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
+    // (32-bit while they are being added to: flushed to the 64-bit counters before they can wrap)
+    uint32_t cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
+    auto flush_counts = [&]() {
+        uint32_t cs = (uint32_t)__shfl((int)cnt_samples, 0, 64), ci = (uint32_t)__shfl((int)cnt_inb, 0, 64), sc = cnt_scan;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sc += __shfl_down(sc, d, 64);
+        if ((threadIdx.x & 63) == 0 && (cs | sc)) {
+            // one 64-byte slot per block (mod kCounterSlots): same-address atomics serialise
+            unsigned long long* slot = a.counters + (size_t)(blockIdx.x % kCounterSlots) * 8;
+            atomicAdd(&slot[0], (unsigned long long)cs);
+            atomicAdd(&slot[1], (unsigned long long)ci);
+            if (sc) atomicAdd(&slot[2], (unsigned long long)sc);
+        }
+        cnt_samples = cnt_inb = cnt_scan = 0;
+    };
     if (PASS == 1 && a.clean_state) {
         for (uint32_t w = blockIdx.x * (uint32_t)kRasterThreads + threadIdx.x; w < a.clean_words;
              w += gridDim.x * (uint32_t)kRasterThreads)
@@ -843,8 +857,8 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                         // counted per wave (a vote and a scalar population count instead of two
                         // 64-bit adds in every lane); the totals are taken from lane 0 at the end
                         const bool counted = chunk * 64u + sidx >= s_count;
-                        cnt_samples += (unsigned long long)__popcll(__ballot(counted));
-                        cnt_inb += (unsigned long long)__popcll(__ballot(counted && inb));
+                        cnt_samples += (uint32_t)__popcll(__ballot(counted));
+                        cnt_inb += (uint32_t)__popcll(__ballot(counted && inb));
                     }
                     if (inb) {
                         const double dist = -z;
@@ -930,6 +944,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
             t[0] = tr_t0; t[1] = tr_t1; t[2] = wall_clock64();
             t[3] = (unsigned long long)total | ((unsigned long long)blockIdx.x << 32);
         }
+        if (PASS == 0 && (uint32_t)__shfl((int)cnt_samples, 0, 64) > 0x40000000u) flush_counts();  // (uniform per wave)
         if (threadIdx.x == 0 && chunk < a.live_cap) {
             if (PASS == 0) {
                 if (live) a.chunk_live[chunk] = 1;
@@ -941,17 +956,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     if (PASS == 0) {
         // cnt_samples / cnt_inb are per-wave totals already (every lane that took part in a vote holds
         // them; lane 0 takes part in every one its wave casts); cnt_scan is per lane
-        cnt_samples = (unsigned long long)__shfl((long long)cnt_samples, 0, 64);
-        cnt_inb = (unsigned long long)__shfl((long long)cnt_inb, 0, 64);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) cnt_scan += __shfl_down(cnt_scan, d, 64);
-        if (lane == 0 && (cnt_samples | cnt_scan)) {
-            // one 64-byte slot per block (mod kCounterSlots): same-address atomics serialise
-            unsigned long long* slot = a.counters + (size_t)(blockIdx.x % kCounterSlots) * 8;
-            atomicAdd(&slot[0], cnt_samples);
-            atomicAdd(&slot[1], cnt_inb);
-            if (cnt_scan) atomicAdd(&slot[2], cnt_scan);
-        }
+        flush_counts();
     }
 }
 
