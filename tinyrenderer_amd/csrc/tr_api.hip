@@ -1052,14 +1052,14 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
             }
             TR_HIP(c, hipMemsetAsync(buf, 0, words * sizeof(unsigned long long), c->stream));
             sa.trace = buf;
-            hipLaunchKernelGGL((k_shade<false, true>), sgrid, dim3(256), 0, c->stream, sa);
+            hipLaunchKernelGGL((k_shade<false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
             TR_HIP(c, hipGetLastError());
             std::vector<unsigned long long> h(words);
             TR_HIP(c, hipStreamSynchronize(c->stream));
             TR_HIP(c, hipMemcpy(h.data(), buf, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (FILE* f = std::fopen(shade_trace, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), words, f); std::fclose(f); }
-        } else if (c->frame_has_ext) hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(256), 0, c->stream, sa);
-        else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(256), 0, c->stream, sa);
+        } else if (c->frame_has_ext) hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }
     if (c->mode != 1 && out_mask == TR_OUT_RGBA8) {

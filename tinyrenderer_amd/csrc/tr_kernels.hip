@@ -534,7 +534,7 @@ struct RasterArgs {
     unsigned long long* counters;
     uint32_t* flags;
     NanTable* nan;
-    uint8_t* blk_touched;       // per shade block (32x8 pixels), at [2 * block]: 1 = a winner key was written into it
+    uint8_t* blk_touched;       // per shade block (kShadeBW x kShadeBH pixels), at [2 * block]: 1 = a winner key was written into it
     int blocks_x;
     uint8_t* chunk_live;        // per 64-slot chunk of the frame: 1 = some sample may be a winner
     uint32_t live_cap;          // chunks beyond this are always treated as live
@@ -1113,7 +1113,7 @@ struct ShadeArgs {
     double* rgba_f64;   // optional, 4 per pixel
     uint32_t* flags;
     unsigned long long* cov_counters;  // kCounterSlots x 8, [0] of each slot used
-    // two bytes per 32x8 block, side by side so that one scalar load brings both:
+    // two bytes per shade block, side by side so that one scalar load brings both:
     // [2 b] the winner pass wrote a key into the block this frame, [2 b + 1] rgba8 holds something other than the background
     uint8_t* blk_flags;
     int skip_clean;        // blocks neither touched nor painted are left alone (RGBA8-only resolve, global raster)
@@ -1180,7 +1180,7 @@ __device__ __forceinline__ uint32_t f64_as_u8(double v) {
 // EXT = true: a frame in which some draw asked for an extension shader (DrawExt); draws without one
 // still get the reference's formula, operation for operation.
 template <bool EXT, bool TRACE = false>
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+__global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     unsigned long long tr_t0 = 0;
     if (TRACE) tr_t0 = wall_clock64();
     auto trace_end = [&](uint32_t covered) {

@@ -28,7 +28,7 @@ struct RowArgs {
     uint32_t* refs;            // slot ids, grouped by bin
     uint32_t ref_cap;
     unsigned long long* wkey;  // winner key plane, row-major; only pixels that received a sample are written
-    uint8_t* blk_touched;      // per 32x8 shade block, at [2 * block]
+    uint8_t* blk_touched;      // per shade block, at [2 * block]
     int blocks_x;
     int W, H, nseg;
     int y_lo, y_hi;
