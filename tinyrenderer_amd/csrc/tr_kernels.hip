@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         const bool touched = f_touched != 0 || (a.nan && f_nan != kNanEmpty);
         const bool painted = f_painted != 0;
         if (!touched && !painted) { trace_end(0xFFFFFFFFu); return; }  // (nobody writes the flags on this path)
-        __syncthreads();  // every wave has read the flags before thread 0 rewrites them
+        // (the workgroup is one wave: every lane has read the flags before lane 0 rewrites them)
         if (!touched) {
             if (live) a.rgba8[pix] = 0xFF000000u;  // BLACK, helpers/mod.rs:22
             if (threadIdx.x == 0) a.blk_flags[2u * blk + 1u] = 0;
@@ -1236,7 +1236,8 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     if ((threadIdx.x & 63) == 0 && nwin)
         atomicAdd(&a.cov_counters[(size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8], nwin);
     {
-        const int any = __syncthreads_or(has ? 1 : 0);
+        static_assert(kShadeBW * kShadeBH == 64, "the shade workgroup is one wave: votes instead of barriers");
+        const bool any = nwin != 0ull;
         if (threadIdx.x == 0) {
             a.blk_flags[2u * blk + 1u] = any ? 1 : 0;
             if (a.self_clean) a.blk_flags[2u * blk] = 0;
