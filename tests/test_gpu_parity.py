@@ -346,6 +346,33 @@ def test_scanline_record_overflow_falls_back(oracle, monkeypatch):
             assert g["counters"][k] == o["counters"][k], (cap, k)
 
 
+def test_raster_workgroup_sizes(oracle, monkeypatch):
+    """k_raster with 128 and 256 threads per chunk (chosen by the number of live contexts; pinned
+    here with TR_RASTER_THREADS) and with a second context alive: same frame, same counters."""
+    from tinyrenderer_amd.model_renderer import ModelRendererState
+
+    W, Hh = 400, 300
+    draws = _head_scene(W, Hh, with_eye=True)
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    for threads in ("128", "256"):
+        monkeypatch.setenv("TR_RASTER_THREADS", threads)
+        g = SU.gpu_render(W, Hh, draws, mode=0)
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], (threads, k)
+    monkeypatch.delenv("TR_RASTER_THREADS")
+    other = ModelRendererState(64, 64)
+    try:
+        g = SU.gpu_render(W, Hh, draws, mode=0)
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], k
+    finally:
+        other.close()
+
+
 def test_counters_over_an_extended_frame(oracle):
     """draw, fast resolve (wipes the planes), draw, resolve: the depth pass of the whole frame is
     redone, but every sample is counted once."""

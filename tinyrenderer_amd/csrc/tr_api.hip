@@ -6,6 +6,7 @@
 #include "tr_tile.hip"
 #include "tr_rows.hip"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -68,6 +69,8 @@ struct tr_context {
     uint32_t* flip_buf = nullptr;    // tr_read_rgba8(flip): the presented image, flipped on the device
     uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
+    bool counted = false;            // in g_live_contexts
+    int raster_threads = 0;          // TR_RASTER_THREADS=128|256 pins the raster workgroup size (0: by live contexts)
     bool small_path = true;          // TR_SMALL_TRIS=0 disables k_small
     uint32_t small_draw_tris = 65536; // draws with at least this many triangles use it (TR_SMALL_DRAW)
     uint32_t small_res = kSmallRes;  // TR_SMALL_RES
@@ -245,7 +248,7 @@ void use_state(tr_context* c, int idx) {
     c->nan = c->nan_both + idx;
 }
 
-constexpr int kRasterBlocks = 4096;
+constexpr int kRasterWaves = 4096 * 4;  // waves of a raster launch, whatever the workgroup size
 constexpr int kRowBinBlocks = 1024;
 constexpr int kScanlineBlocks = 2048;
 constexpr int kRowGrid = 256 * 15;  // waves: 15 per CU fit the LDS (10.3 KB each)
@@ -283,6 +286,21 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.trace_cap = 0;
 }
 
+std::atomic<int> g_live_contexts{0};
+
+template <int PASS>
+void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block, hipStream_t stream, const RasterArgs& ra) {
+#define TR_LAUNCH(PC, DB, TH) hipLaunchKernelGGL((k_raster<PASS, PC, DB, TH>), grid, block, 0, stream, ra)
+    if (threads == 128) {
+        if (dbg) { if (precheck) TR_LAUNCH(true, true, 128); else TR_LAUNCH(false, true, 128); }
+        else { if (precheck) TR_LAUNCH(true, false, 128); else TR_LAUNCH(false, false, 128); }
+    } else {
+        if (dbg) { if (precheck) TR_LAUNCH(true, true, 256); else TR_LAUNCH(false, true, 256); }
+        else { if (precheck) TR_LAUNCH(true, false, 256); else TR_LAUNCH(false, false, 256); }
+    }
+#undef TR_LAUNCH
+}
+
 // passes 0 / 1 over the half range [h_lo, h_hi)
 int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool use_live = false, bool rec_ready = false) {
     RasterArgs ra;
@@ -299,9 +317,11 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
         ra.trace = trace_buf;
         ra.trace_cap = kTraceCap;
     }
-    int grid_blocks = kRasterBlocks;
+    // workgroup size: see k_raster; frames in flight are recognised by a second live context on the device
+    int threads = c->raster_threads ? c->raster_threads : (g_live_contexts.load() > 1 ? 128 : 256);
+    int grid_blocks = kRasterWaves * 64 / threads;
     if (const char* e = std::getenv("TR_RASTER_BLOCKS")) grid_blocks = std::atoi(e);
-    dim3 grid(grid_blocks), block(kRasterThreads);
+    dim3 grid(grid_blocks), block(threads);
     struct TraceDump {
         tr_context* c; int pass; const char* path; unsigned long long* buf;
         ~TraceDump() {
@@ -321,13 +341,7 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
     }
     if (pass == 0) {
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
-        if (dbg) {
-            if (c->precheck) hipLaunchKernelGGL((k_raster<0, true, true>), grid, block, 0, c->stream, ra);
-            else hipLaunchKernelGGL((k_raster<0, false, true>), grid, block, 0, c->stream, ra);
-        } else {
-            if (c->precheck) hipLaunchKernelGGL((k_raster<0, true, false>), grid, block, 0, c->stream, ra);
-            else hipLaunchKernelGGL((k_raster<0, false, false>), grid, block, 0, c->stream, ra);
-        }
+        launch_k_raster<0>(c->precheck, dbg, threads, grid, block, c->stream, ra);
         if (c->small_any) {
             const dim3 sg((h_hi - h_lo + 255u) / 256u);
             if (c->precheck) hipLaunchKernelGGL((k_small<0, true>), sg, dim3(256), 0, c->stream, ra, c->half_live);
@@ -340,13 +354,7 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
         // measured on MI355X (4K african_head): the winner pass is faster without the filter
         // (44 vs 52 us), the depth pass with it (71 vs 93 us)
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
-        if (dbg) {
-            if (c->precheck_winner) hipLaunchKernelGGL((k_raster<1, true, true>), grid, block, 0, c->stream, ra);
-            else hipLaunchKernelGGL((k_raster<1, false, true>), grid, block, 0, c->stream, ra);
-        } else {
-            if (c->precheck_winner) hipLaunchKernelGGL((k_raster<1, true, false>), grid, block, 0, c->stream, ra);
-            else hipLaunchKernelGGL((k_raster<1, false, false>), grid, block, 0, c->stream, ra);
-        }
+        launch_k_raster<1>(c->precheck_winner, dbg, threads, grid, block, c->stream, ra);
     }
     TR_HIP(c, hipGetLastError());
     return TR_OK;
@@ -495,6 +503,10 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_RASTER_THREADS")) {
+        const int t = std::atoi(e);
+        if (t == 128 || t == 256) c->raster_threads = t;
+    }
     if (const char* e = std::getenv("TR_SMALL_TRIS")) c->small_path = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SMALL_RES")) c->small_res = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SMALL_DRAW")) c->small_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -569,11 +581,14 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (rc != TR_OK) return bail(rc);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     *out_ctx = c;
+    c->counted = true;
+    g_live_contexts.fetch_add(1);
     return TR_OK;
 }
 
 void tr_destroy(tr_context* c) {
     if (!c) return;
+    if (c->counted) g_live_contexts.fetch_sub(1);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
