@@ -43,7 +43,7 @@ for k in sorted(names):
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         e["hbm_bytes_per_launch"] = int(2 * e["FETCH_SIZE"] * 1024 + e["WRITE_SIZE"] * 1024)
     pmc["kernels"][k] = e
-sh = pmc["kernels"].get("tr::k_shade", {})
+sh = next((v for k, v in pmc["kernels"].items() if k.startswith("tr::k_shade")), {})
 if "hbm_bytes_per_launch" in sh:
     pmc["k_shade_hbm_bytes_per_launch"] = sh["hbm_bytes_per_launch"]
 json.dump(pmc, open(f"profiles/{tag}_hbm_pmc_4k.json", "w"), indent=1)
@@ -51,5 +51,8 @@ b = os.path.join(src, "bench.json")
 if os.path.exists(b):
     lines = [l for l in open(b) if l.startswith("{")]
     if lines:
-        open(f"profiles/{tag}_bench_4k.json", "w").write(lines[-1])
+        line = json.loads(lines[-1])
+        if line.get("roofline", {}).get("traffic") is None and "k_shade_hbm_bytes_per_launch" in pmc:
+            line["roofline"]["traffic"] = pmc["k_shade_hbm_bytes_per_launch"]  # (bench.py ran before this file existed)
+        open(f"profiles/{tag}_bench_4k.json", "w").write(json.dumps(line) + "\n")
 print(json.dumps(pmc, indent=1)[:3000])
