@@ -559,7 +559,7 @@ def test_device_arithmetic_shortcuts_are_exact():
 def test_context_lifecycle_leaves_no_device_memory_behind(oracle):
     """Contexts of several sizes created, used (every raster mode, extension shaders, a shadow map,
     late plane requests) and destroyed: the device's free memory comes back, results stay right."""
-    import torch
+    import ctypes as C
 
     from tinyrenderer_amd import _ffi
     from tinyrenderer_amd.model_renderer import (ModelRendererState, ShadeExt, ShadowMap, clear_screen,
@@ -588,13 +588,20 @@ def test_context_lifecycle_leaves_no_device_memory_behind(oracle):
     ref = cycle(96, 64, 0)
     o = SU.oracle_render(oracle, 96, 64, _head_scene(96, 64, with_eye=True))
     assert np.array_equal(ref[0], o["present"]) and np.array_equal(ref[1], o["key"])
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
+    # (the HIP runtime the library itself is linked against: no second runtime is initialised for this)
+    hip = C.CDLL("libamdhip64.so.7")
+
+    def free_bytes():
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    free0 = free_bytes()
     for k in range(12):
         W, Hh = (96, 64) if k % 3 == 0 else ((640, 360) if k % 3 == 1 else (33, 1000))
         got = cycle(W, Hh, k % 3)
         if (W, Hh) == (96, 64):
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
-    torch.cuda.synchronize()
-    free1, _ = torch.cuda.mem_get_info()
+    free1 = free_bytes()
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned"
