@@ -13,6 +13,10 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetc
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- $BENCH > "$OUT/write.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d "$OUT/sq" -o pmc -- $BENCH > "$OUT/sq.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/tcc" -o pmc -- $BENCH > "$OUT/tcc.log" 2>&1
-# the headline command itself (default contexts), for the committed bench line
+# the headline command itself (four contexts in flight): kernel durations there include the time a kernel
+# shares the GPU with those of three other frames; tools/overlap_report.py summarises the overlap
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o ks -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --profile-frames 0 > "$OUT/stats4.log" 2>&1
+python3 tools/overlap_report.py "$(ls $OUT/stats4/*/ks_kernel_trace.csv $OUT/stats4/ks_kernel_trace.csv 2>/dev/null | head -1)" > "$OUT/overlap4.txt" 2>&1 || true
+# the headline command without the profiler, for the committed bench line
 timeout -k 10 300 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 ls -R "$OUT" | head -40

@@ -27,6 +27,11 @@ def counters(sub):
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats_4k.csv")
+stats4 = glob.glob(os.path.join(src, "stats4", "**", "*kernel_stats.csv"), recursive=True)
+if stats4:
+    shutil.copy(stats4[0], f"profiles/{tag}_kernel_stats_4k_4ctx.csv")
+if os.path.exists(os.path.join(src, "overlap4.txt")):
+    shutil.copy(os.path.join(src, "overlap4.txt"), f"profiles/{tag}_overlap_4k_4ctx.txt")
 pmc = {"source": "tools/collect_profiles.sh: rocprofv3 --pmc, one counter set per run, python3 bench.py --contexts 1 "
                  "--steps 40 --warmup 5, african_head 3840x2160, global raster, RGBA8-only resolve",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per launch as rocprofv3 reports them, averaged over launches",
