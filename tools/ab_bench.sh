@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of two builds of the library on one GPU box (through gpurun, from the repo root):
-#   bash tools/ab_bench.sh variants/a.so variants/b.so [rounds=3] [contexts=4]
+# A/B of builds of the library on one GPU box (through gpurun, from the repo root):
+#   bash tools/ab_bench.sh rounds contexts variants/a.so variants/b.so [...]
 # alternates `bench.py` between them (TINYRENDERER_HIP_LIB) and prints frames/s and stage times.
-A=$1; B=$2; R=${3:-3}; CTX=${4:-4}
+R=$1; CTX=$2; shift 2
 for i in $(seq 1 "$R"); do
-  for lib in "$A" "$B"; do
+  for lib in "$@"; do
     TINYRENDERER_HIP_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --contexts "$CTX" --steps 600 --warmup 50 --no-cpu-baseline > /tmp/ab.json 2>/tmp/ab.err || { cat /tmp/ab.err; exit 1; }
     python3 -c "
 import json,sys
