@@ -476,34 +476,81 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __r
     }
 }
 
-// single block: the whole scan for up to a few tiles (one launch instead of three)
+// single block: the whole scan of a small draw (one launch instead of three; the tail of the fused
+// k_setup).  Thread t owns 8 consecutive entries in each of up to 4 rows of 2 048: a wave's loads and
+// stores are contiguous 2 KB (a thread that owns one long run makes every lane of a load touch a line
+// of its own: 3 us per 4 096 entries, measured), all rows are in flight before the first is needed,
+// and one barrier serves the row scans.  Per-wave sums are 32-bit with the wrap detected (an
+// entry is below 2^24, a thread's run below 2^27), the running base is 64-bit: a total beyond 2^32 - 1
+// raises the overflow flag either way.
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
                                               uint32_t* flags) {
+    constexpr int kRows = 4, kRun = 8;
+    constexpr uint32_t kRow = (uint32_t)kScanThreads * kRun;
     __shared__ unsigned long long carry;
+    __shared__ uint32_t wtot[kRows][kScanThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = off[0];
     __syncthreads();
-    for (uint32_t t0 = 0; t0 < n; t0 += kScanTile) {
-        uint32_t begin = t0 + threadIdx.x * kScanPer;
-        uint32_t v[kScanPer];
-        uint32_t s = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += kRow * kRows) {
+        uint32_t v[kRows][kRun];
+        uint32_t inc[kRows], own[kRows];
+        bool wrapped = false;
 #pragma unroll
-        for (int i = 0; i < kScanPer; ++i) {
-            v[i] = (begin + i < n) ? cnt[begin + i] : 0u;
-            s += v[i];
+        for (int r = 0; r < kRows; ++r) {
+            const uint32_t begin = t0 + (uint32_t)r * kRow + threadIdx.x * kRun;
+            uint32_t sum = 0;
+            // (cnt and begin are 8-byte aligned: the counts of a triangle's two halves come as one load)
+#pragma unroll
+            for (int q = 0; q < kRun / 2; ++q) {
+                uint2 two = make_uint2(0u, 0u);
+                if (begin + 2 * q + 1 < n) two = *reinterpret_cast<const uint2*>(cnt + begin + 2 * q);
+                else if (begin + 2 * q < n) two.x = cnt[begin + 2 * q];
+                v[r][2 * q] = two.x;
+                v[r][2 * q + 1] = two.y;
+                sum += two.x + two.y;
+            }
+            own[r] = sum;
         }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan(s, &tot);
-        unsigned long long base = carry;
-        uint32_t run = (uint32_t)base + ex;
 #pragma unroll
-        for (int i = 0; i < kScanPer; ++i) {
-            run += v[i];
-            if (begin + i < n) off[begin + i + 1] = run;
+        for (int r = 0; r < kRows; ++r) {
+            uint32_t x = own[r];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(x, d, 64);
+                if (lane >= d) {
+                    x += t;
+                    wrapped |= x < t;
+                }
+            }
+            inc[r] = x;
+            if (lane == 63) wtot[r][wave] = x;
         }
         __syncthreads();
+        unsigned long long base = carry;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            unsigned long long before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < kScanThreads / 64; ++w) {
+                const unsigned long long t = wtot[r][w];
+                if (w < wave) before += t;
+                all += t;
+            }
+            uint32_t run = (uint32_t)(base + before) + (inc[r] - own[r]);
+            const uint32_t begin = t0 + (uint32_t)r * kRow + threadIdx.x * kRun;
+#pragma unroll
+            for (int e = 0; e < kRun; ++e) {
+                run += v[r][e];
+                if (begin + e < n) off[begin + e + 1] = run;  // off[j+1] = inclusive sum through j
+            }
+            base += all;
+        }
+        if (wrapped) atomicOr(flags, 1u << 4);
+        __syncthreads();  // (everyone has read carry and wtot)
         if (threadIdx.x == 0) {
-            carry = base + tot;
-            if (base + tot > 0xFFFFFFFFull) atomicOr(flags, 1u << 4);
+            carry = base;
+            if (base > 0xFFFFFFFFull) atomicOr(flags, 1u << 4);
         }
         __syncthreads();
     }
