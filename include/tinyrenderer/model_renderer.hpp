@@ -176,6 +176,8 @@ class ShadowMap {  // the z plane of a state in which the scene was drawn from t
     ShadowMap(const ShadowMap&) = delete;
     ShadowMap& operator=(const ShadowMap&) = delete;
     ~ShadowMap() { tr_shadow_map_destroy(map_); }
+    // a new snapshot of `light_state` (same size) into this map: no allocation, no host wait
+    void update(ModelRendererState& light_state) { light_state.check(tr_shadow_map_update(map_, light_state.context()), "tr_shadow_map_update"); }
     const tr_shadow_map* handle() const { return map_; }
 
   private:

@@ -138,7 +138,12 @@ int tr_draw(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params);
  *   rgb_c = min(ambient + (lit * (diff * intensity + specular_strength * spec)) * a_c, 255)
  * tr_shadow_map_create snapshots the z plane of a context in which the scene was drawn from the
  * light (any size); the map is independent of that context afterwards and may serve any number of
- * frames on the same device. */
+ * frames on the same device.  A light frame that has not been resolved is resolved for depth only
+ * (no shading).  tr_shadow_map_update takes a new snapshot into an existing map of the same size (a
+ * light that moves every frame: no allocation).  Neither call waits on the host: the copy runs on the
+ * light context's stream, a context whose frame uses the map makes its shade pass wait for it, and an
+ * update waits for the shade passes that still read the old contents.  tr_shadow_map_destroy must not
+ * be called while a frame that refers to the map is still to be resolved. */
 enum { TR_SHADE_REFERENCE = 0, TR_SHADE_GOURAUD = 1, TR_SHADE_PHONG = 2 };
 typedef struct tr_shadow_map tr_shadow_map;
 typedef struct tr_shade_ext {
@@ -153,6 +158,7 @@ typedef struct tr_shade_ext {
     double shadow_dim;
 } tr_shade_ext;
 int tr_shadow_map_create(tr_context* light_ctx, tr_shadow_map** out_map);
+int tr_shadow_map_update(tr_shadow_map* map, tr_context* light_ctx);
 void tr_shadow_map_destroy(tr_shadow_map* map);
 int tr_draw_ext(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params, const tr_shade_ext* ext);
 

@@ -34,27 +34,41 @@ def main():
     m = shadow_from_view(sh, W, H, light_sh, M, M)
     light, cam = ModelRendererState(M, M), ModelRendererState(W, H)
 
-    def frame(keep=False):
+    state = {"sm": None}
+
+    def frame(keep=False, reuse=True):
         clear_screen(light)
-        render_mesh_component(light, mc, light_sh)
-        light.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z)
-        sm = ShadowMap(light, keep_host_copy=keep)
+        render_mesh_component(light, mc, light_sh)  # (not resolved here: the snapshot resolves for depth only)
+        if state["sm"] is not None and reuse and not keep:
+            state["sm"].update(light)  # no allocation, no host wait
+        else:
+            if state["sm"] is not None:
+                state["sm"].close()
+            state["sm"] = ShadowMap(light, keep_host_copy=keep)
+        sm = state["sm"]
         ext = ShadeExt(model=_ffi.TR_SHADE_PHONG, specular_map=spec, specular_strength=0.6, shadow=sm,
                        shadow_from_view=m, shadow_bias=0.01, shadow_dim=0.3)
         clear_screen(cam)
         render_mesh_component(cam, mc, sh, ext)
         cam.resolve(_ffi.TR_OUT_RGBA8)
-        cam.synchronize()
         return sm, ext
 
-    times = []
-    for it in range(12):
+    for label, reuse, sync_each in (("a new map per frame, host waits for every frame", False, True),
+                                    ("one map updated in place, host waits for every frame", True, True),
+                                    ("one map updated in place, 200 frames queued", True, False)):
+        n = 12 if sync_each else 200
+        for it in range(3):
+            frame(reuse=reuse)
+        cam.synchronize()
         t0 = time.perf_counter()
-        sm, ext = frame()
-        times.append(time.perf_counter() - t0)
-        sm.close()
-    print(f"{W}x{H}, shadow map {M}x{M}: light pass + camera pass, median {np.median(times[2:]) * 1e3:.3f} ms per frame "
-          f"({1.0 / np.median(times[2:]):.0f} frames/s, one context)", flush=True)
+        for it in range(n):
+            frame(reuse=reuse)
+            if sync_each:
+                cam.synchronize()
+        cam.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"{W}x{H}, shadow map {M}x{M}, light pass + camera pass, {label}: {dt * 1e3:.3f} ms per frame "
+              f"({1.0 / dt:.0f} frames/s, one context each)", flush=True)
     sm, ext = frame(keep=True)
     key, present = cam.winner_keys(), cam.present()
     print("flags", hex(cam.status_flags()), cam.counters(), flush=True)
@@ -65,7 +79,7 @@ def main():
           f"colour max diff {d.max()} LSB, pixels differing {(d.max(axis=2) > 0).sum()}", flush=True)
     if out_png:
         helpers.write_rgba_img_to_file(out_png, present)
-    sm.close()
+    state["sm"].close()
     light.close()
     cam.close()
 

@@ -166,3 +166,54 @@ def test_gpu_ext_argument_checks():
         assert (st.present() == a).all()
     finally:
         st.close()
+
+
+@pytest.mark.gpu
+def test_gpu_shadow_map_update_and_depth_only_snapshot():
+    """A map taken from a light frame nobody resolved (resolved for depth only: the image of that frame
+    is still right when asked for afterwards), then refreshed in place from a second light
+    (tr_shadow_map_update: no allocation, no host wait) while the camera context keeps rendering."""
+    mc, sh, light_a = _scene("diablo")
+    light_b = scenes.shader_for(mc, LW, LH, eye=(-1.4, 0.6, 1.5))
+    light = ModelRendererState(LW, LH)
+    cam = ModelRendererState(W, H)
+    spec = scenes.load_specular("diablo")
+
+    def light_pass(lsh):
+        clear_screen(light)
+        render_mesh_component(light, mc, lsh)  # (no resolve: the snapshot does what it needs)
+
+    def camera_pass(sm, lsh):
+        ext = ShadeExt(model=_ffi.TR_SHADE_PHONG, specular_map=spec, specular_strength=0.6, shadow=sm,
+                       shadow_from_view=shadow_from_view(sh, W, H, lsh, LW, LH), shadow_bias=0.01, shadow_dim=0.3)
+        clear_screen(cam)
+        render_mesh_component(cam, mc, sh, ext)
+        cam.resolve(_ffi.TR_OUT_RGBA8)
+        return ext
+
+    light_pass(light_a)
+    sm = ShadowMap(light, keep_host_copy=True)
+    o_light = SU.oracle_render(oracle_ffi, LW, LH, [(mc, light_a)])
+    assert (o_light["z"].view(np.uint64) == sm.z_reference().view(np.uint64)).all()
+    assert np.array_equal(light.present(), o_light["present"])  # the colour the snapshot skipped
+    for lsh in (light_a, light_b, light_a, light_b):
+        light_pass(lsh)
+        sm.update(light)
+        ext = camera_pass(sm, lsh)
+        got = cam.present()
+        o = SU.oracle_render(oracle_ffi, W, H, [(mc, sh, ShadeExt(model=ext.model, specular_map=spec, specular_strength=0.6,
+                                                                     shadow=HostShadow(sm.z_reference()),
+                                                                     shadow_from_view=ext.shadow_from_view, shadow_bias=0.01,
+                                                                     shadow_dim=0.3))])
+        assert np.abs(o["present"].astype(int) - got.astype(int)).max() <= 1
+    # frames in flight: several light / camera passes queued without a host wait, only the last one read
+    for k in range(6):
+        lsh = light_b if k % 2 else light_a
+        light_pass(lsh)
+        sm.update(light)
+        ext = camera_pass(sm, lsh)
+    got = cam.present()
+    assert np.abs(o["present"].astype(int) - got.astype(int)).max() <= 1  # (the last pass used light_b, like `o`)
+    sm.close()
+    light.close()
+    cam.close()

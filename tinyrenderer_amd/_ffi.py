@@ -42,7 +42,7 @@ EXPORTS = [
     "tr_set_raster_mode", "tr_obj_load", "tr_obj_parse", "tr_obj_counts", "tr_obj_positions", "tr_obj_uvw",
     "tr_obj_normals", "tr_obj_indices", "tr_obj_free", "tr_image_load_rgba8", "tr_image_size", "tr_image_data",
     "tr_image_free", "tr_load_error", "tr_image_write_png", "tr_selftest_arithmetic",
-    "tr_draw_ext", "tr_shadow_map_create", "tr_shadow_map_destroy", "tr_host_alloc", "tr_host_free",
+    "tr_draw_ext", "tr_shadow_map_create", "tr_shadow_map_update", "tr_shadow_map_destroy", "tr_host_alloc", "tr_host_free",
 ]
 
 
@@ -135,6 +135,7 @@ def load():
         "tr_selftest_arithmetic": (i32, [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
         "tr_draw_ext": (i32, [vp, vp, C.POINTER(DrawParams), C.POINTER(ShadeExt)]),
         "tr_shadow_map_create": (i32, [vp, C.POINTER(vp)]),
+        "tr_shadow_map_update": (i32, [vp, vp]),
         "tr_shadow_map_destroy": (None, [vp]),
         "tr_host_alloc": (vp, [C.c_size_t]),
         "tr_host_free": (None, [vp]),

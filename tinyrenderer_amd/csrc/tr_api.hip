@@ -6,11 +6,15 @@
 #include "tr_tile.hip"
 #include "tr_rows.hip"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <new>
 #include <string>
 #include <vector>
@@ -22,10 +26,16 @@ struct tr_texture {
     int w = 0, h = 0;
 };
 
-struct tr_shadow_map {  // extension: a light-view z plane (tr_shadow_map_create)
+struct tr_shadow_map {  // extension: a light-view z plane (tr_shadow_map_create / _update)
     double* dev = nullptr;
     int w = 0, h = 0;
     int device = 0;
+    // The snapshot is a copy on the light context's stream; no host synchronisation: a context whose
+    // frame uses the map makes its stream wait for `ready` before its shade pass and records an event
+    // of its own behind that pass, which the next tr_shadow_map_update waits for before it overwrites.
+    hipEvent_t ready = nullptr;
+    std::mutex lock;  // (consumers may live on different host threads)
+    std::vector<std::pair<const tr_context*, hipEvent_t>> consumed;
 };
 
 struct tr_mesh {
@@ -96,6 +106,7 @@ struct tr_context {
     size_t ndc_cap = 0, nout_cap = 0;
     DrawDev* draw_table = nullptr;
     DrawExt* ext_table = nullptr;    // extension shaders: allocated with the first tr_draw_ext that names one
+    std::vector<tr_shadow_map*> frame_maps;  // shadow maps the draws since tr_clear refer to
     bool frame_has_ext = false;      // some draw since tr_clear uses an extension: k_shade<true>
     DrawDev draw0;                   // host copy of the frame's first draw (a kernel argument of the shade pass)
     uint32_t draw_cap = 4096;
@@ -136,6 +147,8 @@ struct tr_context {
     double prof_ms[ST_COUNT] = {0};
     uint64_t prof_n[ST_COUNT] = {0};
 };
+
+static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour);
 
 namespace {
 
@@ -446,9 +459,10 @@ int settle_bin_overflow(tr_context* c) {
     return fail(c, TR_ERR_UNSUPPORTED, "tile bin list kept overflowing");
 }
 
-int need_plane(tr_context* c, uint32_t plane) {
+int need_plane(tr_context* c, uint32_t plane, bool colour = true) {
     if (!(c->resolved && (c->resolved_mask & plane))) {
-        int rc = tr_resolve(c, (c->resolved ? c->resolved_mask : 0u) | plane);
+        // (colour == false only spares the shading of a frame nobody has resolved yet)
+        int rc = resolve_frame(c, (c->resolved ? c->resolved_mask : 0u) | plane, colour || c->resolved);
         if (rc != TR_OK) return rc;
     }
     return settle_bin_overflow(c);
@@ -478,7 +492,7 @@ int read_plane(tr_context* c, const T* dev, T* out, int layout, int comps) {
 
 extern "C" {
 
-const char* tr_version(void) { return "tinyrenderer_hip abi=3 arch=gfx950 fp=f64 contract=off"; }
+const char* tr_version(void) { return "tinyrenderer_hip abi=4 arch=gfx950 fp=f64 contract=off"; }
 
 const char* tr_last_error(const tr_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -640,6 +654,7 @@ int tr_clear(tr_context* c) {
     c->resolved = false;
     c->resolved_mask = 0;
     c->frame_has_ext = false;
+    c->frame_maps.clear();
     c->small_any = false;
     return TR_OK;
 }
@@ -733,31 +748,56 @@ int tr_texture_destroy(tr_context* c, tr_texture* t) {
 
 int tr_draw(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p) { return tr_draw_ext(c, mesh, p, nullptr); }
 
+// Snapshot of the light context's z plane into m (allocated, same size).  A frame that has not been
+// resolved yet is resolved for depth only: no shading, no colour plane (k_shade with TR_OUT_Z alone).
+static int shadow_snapshot(tr_context* light, tr_shadow_map* m) {
+    int rc = need_plane(light, TR_OUT_Z, /*colour=*/false);
+    if (rc != TR_OK) return rc;
+    {
+        std::lock_guard<std::mutex> g(m->lock);
+        for (auto& ce : m->consumed)  // shade passes that may still read the old contents
+            TR_HIP(light, hipStreamWaitEvent(light->stream, ce.second, 0));
+    }
+    const size_t bytes = (size_t)m->w * m->h * sizeof(double);
+    TR_HIP(light, hipMemcpyAsync(m->dev, light->z_out, bytes, hipMemcpyDeviceToDevice, light->stream));
+    TR_HIP(light, hipEventRecord(m->ready, light->stream));
+    return TR_OK;
+}
+
 int tr_shadow_map_create(tr_context* light, tr_shadow_map** out) {
     if (!light || !out) return TR_ERR_INVALID;
     *out = nullptr;
     TR_HIP(light, hipSetDevice(light->device));
-    int rc = need_plane(light, TR_OUT_Z);
-    if (rc != TR_OK) return rc;
     tr_shadow_map* m = new (std::nothrow) tr_shadow_map();
     if (!m) return fail(light, TR_ERR_OOM, "shadow map");
     m->w = light->W; m->h = light->H; m->device = light->device;
     const size_t bytes = (size_t)m->w * m->h * sizeof(double);
-    if (hipMalloc(&m->dev, bytes) != hipSuccess) { delete m; return fail(light, TR_ERR_OOM, "shadow map"); }
-    if (hipMemcpyAsync(m->dev, light->z_out, bytes, hipMemcpyDeviceToDevice, light->stream) != hipSuccess ||
-        hipStreamSynchronize(light->stream) != hipSuccess) {
-        (void)hipFree(m->dev);
-        delete m;
-        return fail(light, TR_ERR_HIP, "shadow map copy");
+    int rc = TR_OK;
+    if (hipMalloc(&m->dev, bytes) != hipSuccess) rc = fail(light, TR_ERR_OOM, "shadow map");
+    else if (hipEventCreateWithFlags(&m->ready, hipEventDisableTiming) != hipSuccess) rc = fail(light, TR_ERR_HIP, "shadow map event");
+    else rc = shadow_snapshot(light, m);
+    if (rc != TR_OK) {
+        tr_shadow_map_destroy(m);
+        return rc;
     }
     *out = m;
     return TR_OK;
 }
 
+int tr_shadow_map_update(tr_shadow_map* m, tr_context* light) {
+    if (!m || !light) return TR_ERR_INVALID;
+    if (m->device != light->device || m->w != light->W || m->h != light->H)
+        return fail(light, TR_ERR_INVALID, "shadow map and light context differ in size or device");
+    TR_HIP(light, hipSetDevice(light->device));
+    return shadow_snapshot(light, m);
+}
+
 void tr_shadow_map_destroy(tr_shadow_map* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    (void)hipFree(m->dev);
+    (void)hipFree(m->dev);  // (synchronises the device: no pass is reading the map any more)
+    if (m->ready) (void)hipEventDestroy(m->ready);
+    for (auto& ce : m->consumed) (void)hipEventDestroy(ce.second);
     delete m;
 }
 
@@ -787,7 +827,11 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         if (ext_draw) {
             e.model = x->model;
             if (x->specular_map) { e.spec = x->specular_map->dev; e.sw = x->specular_map->w; e.sh = x->specular_map->h; }
-            if (x->shadow) { e.shadow = x->shadow->dev; e.mw = x->shadow->w; e.mh = x->shadow->h; }
+            if (x->shadow) {
+                e.shadow = x->shadow->dev; e.mw = x->shadow->w; e.mh = x->shadow->h;
+                tr_shadow_map* sm = const_cast<tr_shadow_map*>(x->shadow);
+                if (std::find(c->frame_maps.begin(), c->frame_maps.end(), sm) == c->frame_maps.end()) c->frame_maps.push_back(sm);
+            }
             e.shininess = x->shininess; e.strength = x->specular_strength;
             e.bias = x->shadow_bias; e.dim = x->shadow_dim;
             std::memcpy(e.to_light.m, x->shadow_from_view, sizeof(e.to_light.m));
@@ -920,11 +964,18 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     return TR_OK;
 }
 
-int tr_resolve(tr_context* c, uint32_t out_mask) {
+int tr_resolve(tr_context* c, uint32_t out_mask) { return resolve_frame(c, out_mask, true); }
+
+// colour == false (shadow snapshots of an unresolved frame): winner selection and the planes asked
+// for, no shading and no colour plane; RGBA8 is then not part of resolved_mask, so that a later read
+// of the image resolves again.
+static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
     if (!c) return TR_ERR_INVALID;
     TR_HIP(c, hipSetDevice(c->device));
     size_t npix = (size_t)c->W * c->H;
-    out_mask |= TR_OUT_RGBA8;
+    out_mask &= (TR_OUT_RGBA8 | TR_OUT_Z | TR_OUT_TRI_ID | TR_OUT_RGBA_F64 | TR_OUT_KEY);
+    if (colour || (out_mask & TR_OUT_RGBA_F64)) out_mask |= TR_OUT_RGBA8;
+    else out_mask &= ~(uint32_t)TR_OUT_RGBA8;
     if ((out_mask & TR_OUT_Z) && !c->z_out) TR_HIP(c, hipMalloc(&c->z_out, npix * sizeof(double)));
     if ((out_mask & TR_OUT_TRI_ID) && !c->tri_out) TR_HIP(c, hipMalloc(&c->tri_out, npix * sizeof(uint32_t)));
     if ((out_mask & TR_OUT_RGBA_F64) && !c->rgba_f64) TR_HIP(c, hipMalloc(&c->rgba_f64, npix * 4 * sizeof(double)));
@@ -1073,7 +1124,21 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
             TR_HIP(c, hipStreamSynchronize(c->stream));
             TR_HIP(c, hipMemcpy(h.data(), buf, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (FILE* f = std::fopen(shade_trace, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), words, f); std::fclose(f); }
-        } else if (c->frame_has_ext) hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        } else if (c->frame_has_ext) {
+            for (tr_shadow_map* sm : c->frame_maps) TR_HIP(c, hipStreamWaitEvent(c->stream, sm->ready, 0));
+            hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+            for (tr_shadow_map* sm : c->frame_maps) {
+                std::lock_guard<std::mutex> g(sm->lock);
+                auto it = std::find_if(sm->consumed.begin(), sm->consumed.end(), [&](const auto& ce) { return ce.first == c; });
+                if (it == sm->consumed.end()) {
+                    hipEvent_t ev = nullptr;
+                    TR_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    sm->consumed.emplace_back(c, ev);
+                    it = sm->consumed.end() - 1;
+                }
+                TR_HIP(c, hipEventRecord(it->second, c->stream));
+            }
+        }
         else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }

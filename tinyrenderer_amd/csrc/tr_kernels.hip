@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         static_assert(kShadeBW * kShadeBH == 64, "the shade workgroup is one wave: votes instead of barriers");
         const bool any = nwin != 0ull;
         if (threadIdx.x == 0) {
-            a.blk_flags[2u * blk + 1u] = any ? 1 : 0;
+            if (a.out_mask & 1u) a.blk_flags[2u * blk + 1u] = any ? 1 : 0;  // (no colour plane written: what it holds is unchanged)
             if (a.self_clean) a.blk_flags[2u * blk] = 0;
         }
     }
@@ -1411,11 +1411,14 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
             for (int c = 0; c < 3; ++c) col[c] = fmin(dp.ambient + (d * dp.intensity * albedo[c]), 255.0);
             col[3] = 255.0;
         };
-        if (__all(s.draw == 0u)) finish(a.draw0);  // kernel argument: scalar registers
+        // (a resolve for depth only, the snapshot of a shadow map: no shading, no colour plane)
+        if (!(a.out_mask & 1u)) {
+        } else if (__all(s.draw == 0u)) finish(a.draw0);  // kernel argument: scalar registers
         else finish(a.draws[s.draw]);
     }
-    a.rgba8[pix] = f64_as_u8(col[0]) | (f64_as_u8(col[1]) << 8) | (f64_as_u8(col[2]) << 16) |
-                   (f64_as_u8(col[3]) << 24);
+    if (a.out_mask & 1u)
+        a.rgba8[pix] = f64_as_u8(col[0]) | (f64_as_u8(col[1]) << 8) | (f64_as_u8(col[2]) << 16) |
+                       (f64_as_u8(col[3]) << 24);
     if (a.out_mask & 16u) a.key_out[pix] = key;
     if (a.out_mask & 2u) a.z_out[pix] = zval;
     if (a.out_mask & 4u) a.tri_out[pix] = tri;

@@ -124,6 +124,12 @@ class ShadowMap:
         self.width, self.height = light_state.frame_width, light_state.frame_height
         self.z_host = light_state.z_buffer[..., 0] if keep_host_copy else None
 
+    def update(self, light_state):
+        """A new snapshot of `light_state` (same size) into this map: no allocation, no host wait."""
+        _ffi.check(light_state._ctx, self._lib.tr_shadow_map_update(self._handle, light_state._ctx), "tr_shadow_map_update")
+        if self.z_host is not None:
+            self.z_host = light_state.z_buffer[..., 0]
+
     def z_reference(self):
         if self.z_host is None:
             raise ValueError("ShadowMap was created without keep_host_copy")
