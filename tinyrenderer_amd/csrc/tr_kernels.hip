@@ -480,22 +480,26 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __r
 // k_setup).  Thread t owns 8 consecutive entries in each of up to 4 rows of 2 048: a wave's loads and
 // stores are contiguous 2 KB (a thread that owns one long run makes every lane of a load touch a line
 // of its own: 3 us per 4 096 entries, measured), all rows are in flight before the first is needed,
-// and one barrier serves the row scans.  Per-wave sums are 32-bit with the wrap detected (an
+// and one barrier per round serves the row scans.  Per-wave sums are 32-bit with the wrap detected (an
 // entry is below 2^24, a thread's run below 2^27), the running base is 64-bit: a total beyond 2^32 - 1
 // raises the overflow flag either way.
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
                                               uint32_t* flags) {
     constexpr int kRows = 4, kRun = 8;
     constexpr uint32_t kRow = (uint32_t)kScanThreads * kRun;
-    __shared__ unsigned long long carry;
-    __shared__ uint32_t wtot[kRows][kScanThreads / 64];
+    // (two sets of wave totals, used in turn: one barrier per round is enough, and nothing waits for a
+    // round's stores before the next round's loads are on their way)
+    __shared__ uint32_t wtot[2][kRows][kScanThreads / 64];
+    __shared__ uint32_t sOut[kRow * kRows + (kRow * kRows >> 5)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry = off[0];
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < n; t0 += kRow * kRows) {
+    // every thread keeps the running base itself (the same value in all of them); off[0] was written
+    // before this launch (tr_clear or the previous draw)
+    unsigned long long base = off[0];
+    bool wrapped = false;
+    int buf = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += kRow * kRows, buf ^= 1) {
         uint32_t v[kRows][kRun];
         uint32_t inc[kRows], own[kRows];
-        bool wrapped = false;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
             const uint32_t begin = t0 + (uint32_t)r * kRow + threadIdx.x * kRun;
@@ -524,36 +528,36 @@ __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, 
                 }
             }
             inc[r] = x;
-            if (lane == 63) wtot[r][wave] = x;
+            if (lane == 63) wtot[buf][r][wave] = x;
         }
         __syncthreads();
-        unsigned long long base = carry;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
             unsigned long long before = 0, all = 0;
 #pragma unroll
             for (int w = 0; w < kScanThreads / 64; ++w) {
-                const unsigned long long t = wtot[r][w];
+                const unsigned long long t = wtot[buf][r][w];
                 if (w < wave) before += t;
                 all += t;
             }
             uint32_t run = (uint32_t)(base + before) + (inc[r] - own[r]);
-            const uint32_t begin = t0 + (uint32_t)r * kRow + threadIdx.x * kRun;
+            const uint32_t local = (uint32_t)r * kRow + threadIdx.x * kRun;
 #pragma unroll
             for (int e = 0; e < kRun; ++e) {
                 run += v[r][e];
-                if (begin + e < n) off[begin + e + 1] = run;  // off[j+1] = inclusive sum through j
+                sOut[local + e + ((local + e) >> 5)] = run;  // (one pad word per 32: no bank conflicts either way)
             }
             base += all;
         }
-        if (wrapped) atomicOr(flags, 1u << 4);
-        __syncthreads();  // (everyone has read carry and wtot)
-        if (threadIdx.x == 0) {
-            carry = base;
-            if (base > 0xFFFFFFFFull) atomicOr(flags, 1u << 4);
-        }
+        // the sums leave through LDS so that a wave stores 256 contiguous bytes per instruction (a thread
+        // storing its own run writes 4 bytes of every 32: 3 us for 8 192 entries, measured)
         __syncthreads();
+#pragma unroll 8
+        for (uint32_t j = threadIdx.x; j < kRow * kRows; j += kScanThreads)
+            if (t0 + j < n) off[t0 + j + 1] = sOut[j + (j >> 5)];  // off[j+1] = inclusive sum through j
+        if (t0 + kRow * kRows < n) __syncthreads();  // (the next round rewrites sOut)
     }
+    if (wrapped || (threadIdx.x == 0 && base > 0xFFFFFFFFull)) atomicOr(flags, 1u << 4);
 }
 
 __global__ __launch_bounds__(kScanThreads) void k_scan_small(const uint32_t* __restrict__ cnt, uint32_t n,
