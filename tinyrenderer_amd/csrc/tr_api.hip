@@ -142,6 +142,7 @@ struct tr_context {
     bool fused_front = true;       // small draws: transform + setup + scan in one launch (TR_FUSED_FRONT)
     uint32_t big_draw_tris = 65536;  // draws at least this large get their records from k_scanlines (TR_BIG_DRAW)
     uint32_t* ticket = nullptr;
+    uint32_t scan_tag = 0;  // tag of the last fused k_setup launch (never 0 in a launch)
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double prof_ms[ST_COUNT] = {0};
@@ -565,8 +566,8 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         if (hipMalloc(&c->tile_list, (size_t)c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     }
-    if (hipMalloc(&c->ticket, 64) != hipSuccess) return bail(TR_ERR_OOM);
-    if (hipMemsetAsync(c->ticket, 0, 64, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMalloc(&c->ticket, 64 * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);  // (k_setup<true>: one word per workgroup)
+    if (hipMemsetAsync(c->ticket, 0, 64 * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     {
         c->nseg = (width + kSegW - 1) / kSegW;
         const size_t n_bins = (size_t)c->nseg * height;
@@ -867,7 +868,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     std::memcpy(pmv.m, p->pmv, sizeof(pmv.m));
     std::memcpy(nmat.m, p->normal_mat, sizeof(nmat.m));
     // small draws (the reference's meshes): one launch does vertex stage + setup + prefix
-    const bool fused = c->fused_front && c->mode != 1 && 2u * (uint64_t)mesh->n_tris <= 8u * (uint64_t)kScanTile;
+    const bool fused = c->fused_front && c->mode != 1 && (uint64_t)mesh->n_tris <= 64u * 256u;  // (at most 64 workgroups: k_setup<true>)
     if (!fused) {
         ProfScope ps(c, ST_TRANSFORM);
         int n = (int)(mesh->n_pos + mesh->n_nrm);
@@ -919,6 +920,8 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.draw_table = c->draw_table;
         if (c->draw_count == 0) c->draw0 = d;
         sa.nrm = mesh->nrm; sa.pmv = pmv; sa.ticket = c->ticket; sa.half_off = c->half_off;
+        if (++c->scan_tag == 0) c->scan_tag = 1;
+        sa.scan_tag = c->scan_tag;
         sa.scan_lo = 2u * tri_base; sa.n_halves = n_halves;
         if (fused) hipLaunchKernelGGL((k_setup<true>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
         else hipLaunchKernelGGL((k_setup<false>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);

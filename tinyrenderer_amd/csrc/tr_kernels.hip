@@ -65,7 +65,8 @@ struct SetupArgs {
     // read back, and the workgroup that finishes last scans the draw's slot counts
     const double* nrm;     // raw normals
     Mat4 pmv;              // perspective * model_view
-    uint32_t* ticket;      // arrival counter of the draw's workgroups (zero between launches)
+    uint32_t* ticket;      // 64 words of 8 bytes: {scan_tag, slot total} of each workgroup of the fused launch
+    uint32_t scan_tag;     // differs from launch to launch (never 0)
     uint32_t* half_off;    // prefix to write: half_off[scan_lo + 1 .. scan_lo + n_halves]
     uint32_t scan_lo, n_halves;
 };
@@ -73,40 +74,83 @@ struct SetupArgs {
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
                                               uint32_t* flags);
 
-__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused);
+__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1);
 
 // FUSED = false: vertex stage read from k_transform's arrays, prefix by the k_scan_* kernels.
-// FUSED = true (draws of up to 8 scan tiles): one launch does transform + setup + scan.
+// FUSED = true (draws of up to 64 workgroups): one launch does transform + setup + scan.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) a.draw_table[a.draw] = a.params;
-    if (k < a.n_tris) setup_triangle(a, k, FUSED);
+    uint32_t c0 = 0, c1 = 0;  // slots of my triangle's two halves
+    if (k < a.n_tris) setup_triangle(a, k, FUSED, c0, c1);
     if (!FUSED) return;
-    // ---- the last workgroup to arrive scans half_cnt of this draw.  Publication follows
-    // cdna_hip_programming.md ("in-launch split-K reduction"): every wave drains its stores, one
-    // agent-scope release before the ticket, one agent-scope acquire in the last arriver.
-    __shared__ uint32_t s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- prefix of the draw's slot counts without a second pass over them: every workgroup scans its
+    // 512 counts in registers, publishes its total as ONE 8-byte word {launch tag, total} (write-through,
+    // `sc1`), and wave 0 adds up the words of the workgroups before it as they appear (`sc1` polls; the
+    // tag is in the same granule as the value, so a word that shows the tag shows the total:
+    // MI355X_MICROARCH.md, data-tagged granules).  No workgroup waits for a later one, and at most 63
+    // workgroups of 256 threads wait at all, far fewer than the GPU holds: every poll ends.  (The first
+    // version let the last workgroup to arrive scan all counts from memory: 7-10 us behind the slowest
+    // workgroup's 11 us; now the prefix is out about 2 us after a workgroup's own triangles.)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ uint32_t s_wtot[4];
+    __shared__ unsigned long long s_base;
+    const uint32_t pair = c0 + c1;  // (< 2^25)
+    uint32_t inc = pair;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;  // (< 2^31)
+    }
+    if (lane == 63) s_wtot[wave] = inc;
     __syncthreads();
+    unsigned long long before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long t = s_wtot[w];
+        if (w < wave) before += t;
+        tot += t;
+    }
+    uint32_t* off = a.half_off + a.scan_lo;
+    unsigned long long* agg = reinterpret_cast<unsigned long long*>(a.ticket);
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = t == gridDim.x - 1u ? 1u : 0u;
+        const unsigned long long word = ((unsigned long long)a.scan_tag << 32) | (tot > 0xFFFFFFFFull ? 0xFFFFFFFFull : tot);
+        __hip_atomic_store(&agg[blockIdx.x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tot > 0xFFFFFFFFull) atomicOr(a.flags, 1u << 4);
+    }
+    if (wave == 0) {
+        unsigned long long sum = lane == 0 ? (unsigned long long)off[0] : 0ull;  // (written before this launch)
+        if ((uint32_t)lane < blockIdx.x) {
+            unsigned long long word = 0;
+            uint32_t tries = 0;
+            for (;;) {
+                word = __hip_atomic_load(&agg[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(word >> 32) == a.scan_tag) break;
+                if (++tries > (1u << 24)) {  // (seconds: something is badly wrong; leave with the overflow flag rather than hang)
+                    atomicOr(a.flags, 1u << 4);
+                    word = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            sum += word & 0xFFFFFFFFull;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+        if (lane == 0) s_base = sum;
     }
     __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next draw
+    const unsigned long long base = s_base;
+    if (k < a.n_tris) {
+        const uint32_t o = (uint32_t)(base + before) + (inc - pair);
+        off[2 * (size_t)k + 1] = o + c0;  // off[j+1] = inclusive sum through j
+        off[2 * (size_t)k + 2] = o + c0 + c1;
     }
-    __syncthreads();
-    scan_in_block(a.half_cnt + a.scan_lo, a.n_halves, a.half_off + a.scan_lo, a.flags);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && base + tot > 0xFFFFFFFFull) atomicOr(a.flags, 1u << 4);
 }
 
-__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused) {
+__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1) {
     const uint32_t* ix = a.idx + 9 * (size_t)k;
     uint32_t iv[3] = {ix[0], ix[3], ix[6]};
     uint32_t it[3] = {ix[1], ix[4], ix[7]};
@@ -358,8 +402,12 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
     }
     if (a.small_flag) a.small_flag[seq] = small ? 1 : 0;  // (every draw writes it: k_small may sweep draws that do not use the path)
     if (a.mode & 1) {  // slots per half
-        a.half_cnt[2 * (size_t)seq] = res0 && !small ? (res0 + 1u) << R.slot_shift : 0u;
-        a.half_cnt[2 * (size_t)seq + 1] = res1 && !small ? (res1 + 1u) << R.slot_shift : 0u;
+        cnt0 = res0 && !small ? (res0 + 1u) << R.slot_shift : 0u;
+        cnt1 = res1 && !small ? (res1 + 1u) << R.slot_shift : 0u;
+        if (!fused) {  // (the fused launch scans them in registers)
+            a.half_cnt[2 * (size_t)seq] = cnt0;
+            a.half_cnt[2 * (size_t)seq + 1] = cnt1;
+        }
     }
 }
 
