@@ -331,6 +331,44 @@ def test_config4_subdivided_mesh_bands(oracle, mode):
     assert np.array_equal(key, g["key"])
 
 
+def test_unfused_front_end_and_draw_sizes_around_the_fused_limit(oracle, monkeypatch):
+    """TR_FUSED_FRONT=0: k_transform + k_setup<false> + the one-launch scan (k_scan_small, several rounds
+    for the head subdivided once) instead of the fused launch; and, fused again, draws just below and
+    above its limit of 64 workgroups (16 384 triangles), the latter through the three-kernel scan."""
+    from tinyrenderer_amd.model_renderer import MeshComponent
+
+    W, Hh = 400, 300
+    head = SU.component("head")
+    once = MeshComponent(scenes.subdivide(head.mesh, 1), head.texture, head.normal_map)  # 9 968 triangles
+    once.transform.set_rotation((0.025, 0.0, 0.0))
+    scenes_ = [_head_scene(W, Hh, with_eye=True), [(once, scenes.shader_for(once, W, Hh))]]
+    refs = [SU.oracle_render(oracle, W, Hh, d) for d in scenes_]
+    monkeypatch.setenv("TR_FUSED_FRONT", "0")
+    for d, o in zip(scenes_, refs):
+        g = SU.gpu_render(W, Hh, d, mode=0)
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], k
+    monkeypatch.delenv("TR_FUSED_FRONT")
+    # 16 384 and 16 385 triangles: a prefix of the twice-subdivided head (39 872 triangles)
+    import copy
+
+    twice = scenes.subdivide(head.mesh, 2)
+    for n in (16384, 16385):
+        part = copy.copy(twice)
+        part.triangles = twice.triangles[:n]
+        mc = MeshComponent(part, head.texture, head.normal_map)
+        mc.transform.set_rotation((0.025, 0.0, 0.0))
+        d = [(mc, scenes.shader_for(mc, W, Hh))]
+        o = SU.oracle_render(oracle, W, Hh, d)
+        g = SU.gpu_render(W, Hh, d, mode=0)
+        info = SU.assert_parity(o, g)
+        assert info["f64_colour_mismatches"] == 0
+        for k in ("samples", "fragments", "scanlines"):
+            assert g["counters"][k] == o["counters"][k], (n, k)
+
+
 def test_scanline_record_overflow_falls_back(oracle, monkeypatch):
     """Global raster: slots beyond the record buffer (TR_SCAN_RECORDS) are rebuilt by every pass;
     results and counters do not depend on the capacity."""
