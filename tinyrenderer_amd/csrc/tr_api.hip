@@ -566,8 +566,8 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         if (hipMalloc(&c->tile_list, (size_t)c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMalloc(&c->pairs, (size_t)c->pair_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     }
-    if (hipMalloc(&c->ticket, 64 * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);  // (k_setup<true>: one word per workgroup)
-    if (hipMemsetAsync(c->ticket, 0, 64 * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipMalloc(&c->ticket, 256 * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);  // (k_setup<true>: one word per workgroup)
+    if (hipMemsetAsync(c->ticket, 0, 256 * sizeof(unsigned long long), c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     {
         c->nseg = (width + kSegW - 1) / kSegW;
         const size_t n_bins = (size_t)c->nseg * height;
@@ -868,7 +868,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     std::memcpy(pmv.m, p->pmv, sizeof(pmv.m));
     std::memcpy(nmat.m, p->normal_mat, sizeof(nmat.m));
     // small draws (the reference's meshes): one launch does vertex stage + setup + prefix
-    const bool fused = c->fused_front && c->mode != 1 && (uint64_t)mesh->n_tris <= 64u * 256u;  // (at most 64 workgroups: k_setup<true>)
+    const bool fused = c->fused_front && c->mode != 1 && (uint64_t)mesh->n_tris <= 16384u;  // (at most 256 workgroups, of 64 threads at the least: k_setup<true>)
     if (!fused) {
         ProfScope ps(c, ST_TRANSFORM);
         int n = (int)(mesh->n_pos + mesh->n_nrm);
@@ -923,7 +923,12 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         if (++c->scan_tag == 0) c->scan_tag = 1;
         sa.scan_tag = c->scan_tag;
         sa.scan_lo = 2u * tri_base; sa.n_halves = n_halves;
-        if (fused) hipLaunchKernelGGL((k_setup<true>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
+        if (fused) {
+            // (measured: 128 threads per workgroup; 64 / 256 cost the orbit rehearsal 1 % / 4 % with four contexts)
+            static const int st = std::getenv("TR_SETUP_THREADS") ? std::atoi(std::getenv("TR_SETUP_THREADS")) : 128;
+            const int threads = (st == 64 || st == 256) ? st : 128;
+            hipLaunchKernelGGL((k_setup<true>), dim3((unsigned)((mesh->n_tris + threads - 1) / threads)), dim3(threads), 0, c->stream, sa);
+        }
         else hipLaunchKernelGGL((k_setup<false>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
         if (c->mode != 1 && !fused) {

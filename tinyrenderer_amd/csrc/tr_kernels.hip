@@ -65,7 +65,7 @@ struct SetupArgs {
     // read back, and the workgroup that finishes last scans the draw's slot counts
     const double* nrm;     // raw normals
     Mat4 pmv;              // perspective * model_view
-    uint32_t* ticket;      // 64 words of 8 bytes: {scan_tag, slot total} of each workgroup of the fused launch
+    uint32_t* ticket;      // 256 words of 8 bytes: {scan_tag, slot total} of each workgroup of the fused launch
     uint32_t scan_tag;     // differs from launch to launch (never 0)
     uint32_t* half_off;    // prefix to write: half_off[scan_lo + 1 .. scan_lo + n_halves]
     uint32_t scan_lo, n_halves;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, 
 __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1);
 
 // FUSED = false: vertex stage read from k_transform's arrays, prefix by the k_scan_* kernels.
-// FUSED = true (draws of up to 64 workgroups): one launch does transform + setup + scan.
+// FUSED = true (draws of up to 256 workgroups of 64 to 256 threads): one launch does transform + setup + scan.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     // 512 counts in registers, publishes its total as ONE 8-byte word {launch tag, total} (write-through,
     // `sc1`), and wave 0 adds up the words of the workgroups before it as they appear (`sc1` polls; the
     // tag is in the same granule as the value, so a word that shows the tag shows the total:
-    // MI355X_MICROARCH.md, data-tagged granules).  No workgroup waits for a later one, and at most 63
-    // workgroups of 256 threads wait at all, far fewer than the GPU holds: every poll ends.  (The first
+    // MI355X_MICROARCH.md, data-tagged granules).  No workgroup waits for a later one, and at most 255
+    // small workgroups wait at all, far fewer than the GPU holds: every poll ends.  (The first
     // version let the last workgroup to arrive scan all counts from memory: 7-10 us behind the slowest
     // workgroup's 11 us; now the prefix is out about 2 us after a workgroup's own triangles.)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,9 +106,10 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     if (lane == 63) s_wtot[wave] = inc;
     __syncthreads();
     unsigned long long before = 0, tot = 0;
+    const int n_waves = (int)(blockDim.x >> 6);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const unsigned long long t = s_wtot[w];
+        const unsigned long long t = w < n_waves ? s_wtot[w] : 0u;
         if (w < wave) before += t;
         tot += t;
     }
@@ -121,11 +122,11 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     }
     if (wave == 0) {
         unsigned long long sum = lane == 0 ? (unsigned long long)off[0] : 0ull;  // (written before this launch)
-        if ((uint32_t)lane < blockIdx.x) {
+        for (uint32_t j = (uint32_t)lane; j < blockIdx.x; j += 64u) {
             unsigned long long word = 0;
             uint32_t tries = 0;
             for (;;) {
-                word = __hip_atomic_load(&agg[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                word = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((uint32_t)(word >> 32) == a.scan_tag) break;
                 if (++tries > (1u << 24)) {  // (seconds: something is badly wrong; leave with the overflow flag rather than hang)
                     atomicOr(a.flags, 1u << 4);
