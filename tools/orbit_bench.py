@@ -41,7 +41,21 @@ def main():
         for s in states:
             s.synchronize()
 
+    def issue(count):
+        for k in range(count):
+            i = k % n_ctx
+            cx = states[i]._ctx
+            lib.tr_clear(cx)
+            lib.tr_draw(cx, meshes[i], C.byref(params[i][k % n]))
+            lib.tr_resolve(cx, _ffi.TR_OUT_RGBA8)
+
     run(16)
+    t0 = time.perf_counter()
+    issue(n)
+    t_issue = time.perf_counter() - t0
+    for s in states:
+        s.synchronize()
+    print(f"host side: {t_issue / n * 1e6:.1f} us per view to issue clear + draw + resolve ({n / t_issue:.0f} views/s if the GPU were free)")
     t0 = time.perf_counter()
     run(n)
     dt = time.perf_counter() - t0
