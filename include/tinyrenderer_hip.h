@@ -143,7 +143,8 @@ int tr_draw(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params);
  * light that moves every frame: no allocation).  Neither call waits on the host: the copy runs on the
  * light context's stream, a context whose frame uses the map makes its shade pass wait for it, and an
  * update waits for the shade passes that still read the old contents.  tr_shadow_map_destroy must not
- * be called while a frame that refers to the map is still to be resolved. */
+ * be called before every context that drew with the map has been cleared (tr_clear) or destroyed: until
+ * then a read of another plane may resolve that frame again. */
 enum { TR_SHADE_REFERENCE = 0, TR_SHADE_GOURAUD = 1, TR_SHADE_PHONG = 2 };
 typedef struct tr_shadow_map tr_shadow_map;
 typedef struct tr_shade_ext {
