@@ -39,16 +39,18 @@ def main():
     def frame(keep=False, reuse=True):
         clear_screen(light)
         render_mesh_component(light, mc, light_sh)  # (not resolved here: the snapshot resolves for depth only)
+        old = None
         if state["sm"] is not None and reuse and not keep:
             state["sm"].update(light)  # no allocation, no host wait
         else:
-            if state["sm"] is not None:
-                state["sm"].close()
+            old = state["sm"]
             state["sm"] = ShadowMap(light, keep_host_copy=keep)
         sm = state["sm"]
         ext = ShadeExt(model=_ffi.TR_SHADE_PHONG, specular_map=spec, specular_strength=0.6, shadow=sm,
                        shadow_from_view=m, shadow_bias=0.01, shadow_dim=0.3)
         clear_screen(cam)
+        if old is not None:
+            old.close()  # (only now: the camera context's last frame referred to it until the clear)
         render_mesh_component(cam, mc, sh, ext)
         cam.resolve(_ffi.TR_OUT_RGBA8)
         return sm, ext
@@ -79,9 +81,9 @@ def main():
           f"colour max diff {d.max()} LSB, pixels differing {(d.max(axis=2) > 0).sum()}", flush=True)
     if out_png:
         helpers.write_rgba_img_to_file(out_png, present)
-    state["sm"].close()
     light.close()
     cam.close()
+    state["sm"].close()  # (after the contexts that drew with it)
 
 
 if __name__ == "__main__":

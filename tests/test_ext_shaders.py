@@ -214,6 +214,6 @@ def test_gpu_shadow_map_update_and_depth_only_snapshot():
         ext = camera_pass(sm, lsh)
     got = cam.present()
     assert np.abs(o["present"].astype(int) - got.astype(int)).max() <= 1  # (the last pass used light_b, like `o`)
-    sm.close()
-    light.close()
     cam.close()
+    light.close()
+    sm.close()  # (after the contexts that drew with it)
