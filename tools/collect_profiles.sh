@@ -17,6 +17,10 @@ timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_sum --outpu
 # shares the GPU with those of three other frames; tools/overlap_report.py summarises the overlap
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o ks -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --profile-frames 0 > "$OUT/stats4.log" 2>&1
 python3 tools/overlap_report.py "$(ls $OUT/stats4/*/ks_kernel_trace.csv $OUT/stats4/ks_kernel_trace.csv 2>/dev/null | head -1)" > "$OUT/overlap4.txt" 2>&1 || true
+# the other configurations of BASELINE.json rehearsed on one GPU: kernel summaries only
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/orbit" -o ks -- python3 tools/orbit_bench.py 512 1920 1080 1 > "$OUT/orbit.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/shadow" -o ks -- python3 tests/manual/diablo_shadow.py 1024 1024 1024 > "$OUT/shadow.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bigmesh" -o ks -- python3 tests/manual/big_mesh_check.py 6 7680 4320 0 0 > "$OUT/bigmesh.log" 2>&1
 # the headline command without the profiler, for the committed bench line
 timeout -k 10 300 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 ls -R "$OUT" | head -40
