@@ -300,7 +300,9 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.trace_cap = 0;
 }
 
-std::atomic<int> g_live_contexts{0};
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_live_contexts[kMaxDevices];  // per device (zero-initialised)
+inline std::atomic<int>& live_contexts(int device) { return g_live_contexts[device >= 0 && device < kMaxDevices ? device : 0]; }
 
 template <int PASS>
 void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block, hipStream_t stream, const RasterArgs& ra) {
@@ -332,7 +334,7 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
         ra.trace_cap = kTraceCap;
     }
     // workgroup size: see k_raster; frames in flight are recognised by a second live context on the device
-    int threads = c->raster_threads ? c->raster_threads : (g_live_contexts.load() > 1 ? 128 : 256);
+    int threads = c->raster_threads ? c->raster_threads : (live_contexts(c->device).load() > 1 ? 128 : 256);
     int grid_blocks = kRasterWaves * 64 / threads;
     if (const char* e = std::getenv("TR_RASTER_BLOCKS")) grid_blocks = std::atoi(e);
     dim3 grid(grid_blocks), block(threads);
@@ -597,13 +599,13 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     *out_ctx = c;
     c->counted = true;
-    g_live_contexts.fetch_add(1);
+    live_contexts(c->device).fetch_add(1);
     return TR_OK;
 }
 
 void tr_destroy(tr_context* c) {
     if (!c) return;
-    if (c->counted) g_live_contexts.fetch_sub(1);
+    if (c->counted) live_contexts(c->device).fetch_sub(1);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);

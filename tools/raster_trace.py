@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-chunk timeline of k_raster (debugging aid).  Run on the GPU box:
-    TR_RASTER_TRACE=gpurun_out/trace python tools/raster_trace.py [W H]
-renders a few frames of the bench scene, then summarises the last depth / winner launch."""
+    TR_RASTER_TRACE=gpurun_out/trace python tools/raster_trace.py [W H [head|diablo]]
+renders a few frames of the bench scene (or of diablo3_pose), then summarises the last depth / winner launch."""
 import os
 import sys
 
@@ -44,6 +44,12 @@ def main():
     from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
 
     draws = bench.build_scene(W, H)
+    if len(sys.argv) > 3 and sys.argv[3] == "diablo":
+        import scene_util as SU
+        from tinyrenderer_amd import scenes
+
+        mc = SU.component("diablo")
+        draws = [(mc, scenes.shader_for(mc, W, H))]
     for suffix in (".depth", ".winner", ".rows"):
         if os.path.exists(path + suffix):
             os.remove(path + suffix)
