@@ -1288,6 +1288,24 @@ __device__ __forceinline__ uint32_t f64_as_u8(double v) {
 }
 
 
+// x^e of the extension shaders' specular term.  A specular MAP holds bytes, so the exponent is almost
+// always an integer in [0, 255]: eight squarings instead of the device library's pow (a few hundred
+// instructions); within a few ulp of it, i.e. far inside the +-1 LSB these shaders are checked to.
+__device__ __forceinline__ double pow_exponent(double x, double e) {
+    if (e >= 0.0 && e <= 255.0 && e == floor(e)) {
+        uint32_t n = (uint32_t)e;
+        double r = 1.0, p = x;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            r = (n & 1u) ? r * p : r;
+            p = p * p;
+            n >>= 1;
+        }
+        return r;
+    }
+    return pow(x, e);
+}
+
 // EXT = false: the reference's shader, the tuned path of every parity test and of the benchmark.
 // EXT = true: a frame in which some draw asked for an extension shader (DrawExt); draws without one
 // still get the reference's formula, operation for operation.
@@ -1440,7 +1458,7 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
                             sample_rgb(e.spec, e.sw, e.sh, u * (double)(e.sw - 1), v * (double)(e.sh - 1), srgb, a.flags);
                             ex = srgb[0];
                         }
-                        spec = pow(fmax(rz, 0.0), ex);
+                        spec = pow_exponent(fmax(rz, 0.0), ex);
                     }
                     double lit = 1.0;
                     if (e.shadow) {
