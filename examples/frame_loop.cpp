@@ -2,13 +2,20 @@
 // the window: same scene (african_head + its inner eyes parented to it), same camera, same
 // per-frame rotation 0.025 * time, same "Frametime (nosync)" print.
 //
-//   frame_loop <asset_dir> [frames=100] [width=853] [height=480] [out.rgba | out.png]
+//   frame_loop <asset_dir> [frames=100] [width=853] [height=480] [out.rgba | out.png | -] [contexts=1]
+//
+// contexts > 1: that many ModelRendererStates (one HIP stream each) take the frames in turn and the host
+// waits only at the end, so that successive frames overlap on the GPU (what bench.py measures).
 //
 // With out.rgba the last frame is written as raw RGBA8 rows (row 0 = top), which is what
 // tests/test_host_cpp.py compares with the oracle.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
 
 #include "tinyrenderer/model_renderer.hpp"
 
@@ -23,7 +30,8 @@ int main(int argc, char** argv) {
     const int frames = argc > 2 ? std::atoi(argv[2]) : 100;
     const size_t frame_width = argc > 3 ? (size_t)std::atoi(argv[3]) : 853;   // main.rs:41-42
     const size_t frame_height = argc > 4 ? (size_t)std::atoi(argv[4]) : 480;
-    const char* out_path = argc > 5 ? argv[5] : nullptr;
+    const char* out_path = argc > 5 && std::strcmp(argv[5], "-") != 0 ? argv[5] : nullptr;
+    const int n_contexts = argc > 6 ? std::max(1, std::atoi(argv[6])) : 1;
     try {
         // main.rs:12-39
         MeshComponent african_head = MeshComponent::from(assets + "/african_head/african_head.obj",
@@ -34,12 +42,17 @@ int main(int argc, char** argv) {
                                                       assets + "/african_head/african_head_eye_inner_nm_tangent.png");
         eye_inner.parent = &african_head;
 
-        ModelRendererState model_renderer_state(frame_width, frame_height);
-        clear_screen(model_renderer_state);
+        std::vector<std::unique_ptr<ModelRendererState>> states;
+        for (int k = 0; k < n_contexts; ++k) {
+            states.emplace_back(new ModelRendererState(frame_width, frame_height));
+            clear_screen(*states.back());
+        }
 
         const double PI = 3.14159265358979323846;
         double total_us = 0.0;
+        const auto loop_begin = std::chrono::steady_clock::now();
         for (int time = 1; time <= frames; ++time) {  // main.rs:57-60
+            ModelRendererState& model_renderer_state = *states[(size_t)(time % n_contexts)];
             const auto before = std::chrono::steady_clock::now();
             clear_screen(model_renderer_state);
 
@@ -59,16 +72,22 @@ int main(int argc, char** argv) {
             do_render_mesh_component(african_head);  // main.rs:272-273
             do_render_mesh_component(eye_inner);
             model_renderer_state.resolve();
-            model_renderer_state.synchronize();
+            if (n_contexts == 1) model_renderer_state.synchronize();
 
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - before).count();
             total_us += us;
-            if (time <= 3 || time == frames)  // main.rs:289-295
+            if (n_contexts == 1 && (time <= 3 || time == frames))  // main.rs:289-295
                 std::printf("\n\"Frametime (nosync)\": %.2fms (%.2f fps)\n", us / 1000.0, 1000000.0 / us);
         }
-        std::printf("%d frames of %zux%zu: mean %.3f ms\n", frames, frame_width, frame_height, total_us / frames / 1000.0);
+        for (auto& st : states) st->synchronize();
+        const double loop_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - loop_begin).count();
+        if (n_contexts == 1)
+            std::printf("%d frames of %zux%zu: mean %.3f ms\n", frames, frame_width, frame_height, total_us / frames / 1000.0);
+        else
+            std::printf("%d frames of %zux%zu, %d contexts in flight: %.3f ms per frame (%.0f frames/s)\n", frames, frame_width,
+                        frame_height, n_contexts, loop_us / frames / 1000.0, 1e6 * frames / loop_us);
         if (out_path) {
-            const RgbaImage img = model_renderer_state.present();
+            const RgbaImage img = states[(size_t)(frames % n_contexts)]->present();
             const std::string op = out_path;
             if (op.size() > 4 && op.compare(op.size() - 4, 4, ".png") == 0) {
                 write_rgba_img_to_file(op, img);
