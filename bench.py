@@ -5,9 +5,11 @@ C++ oracle (a restatement of the reference, NOT the Rust binary) timed on the ho
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one frame: tr_clear + tr_draw + tr_resolve (the window the reference prints as
+A step is a BATCH of --frames-per-step frames (100 by default, so that the driver's 20 steps time
+0.2 s, not 2 ms); a frame is tr_clear + tr_draw + tr_resolve (the window the reference prints as
 "Frametime (nosync)", src/main.rs:58-60,295).  Mesh and textures are resident in HBM before
-the timed region.  N > 1 (launched by torch.distributed.run) shards independent frames over
+the timed region.  After the timed region every context's presented image and counters are checked
+against the oracle's digest of this frame (tests/golden/hashes.json, c3_head_4k): "verified".  N > 1 (launched by torch.distributed.run) shards independent frames over
 ranks with no data-path collective: weak scaling, value = total frames / max-over-ranks time.
 """
 import argparse
@@ -65,8 +67,10 @@ def cpu_baseline(W, H, draws, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)  # 0.2 s: the ramp of four frames in flight is then < 1 %
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-step", type=int, default=100,
+                    help="frames per step per rank: 20 steps = 2 000 frames = 0.2 s, the ramp of four frames in flight is then < 1 %%")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,7 +134,8 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    fps_step = max(1, args.frames_per_step)
+    for _ in range(args.warmup * fps_step):
         frame()
     sync()
     counters = st.counters()
@@ -140,7 +145,7 @@ def main():
     barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps * fps_step):
         frame()
     sync()
     barrier()
@@ -150,9 +155,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_frames = args.steps * world
+    total_frames = args.steps * fps_step * world
     fps = total_frames / elapsed
     frags = counters["fragments"]
+
+    # ---- the frames that were timed, checked: every context's presented image, fragment / sample / scanline
+    # counters and covered pixels against the oracle's digest of this frame (made in the build container by
+    # tests/golden/make_golden.py --big; the oracle itself is timed below as cpu_baseline)
+    verified = None
+    if (W, H) == (3840, 2160):
+        import hashlib
+
+        want = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["c3_head_4k"]
+        verified = True
+        for k, s_ in enumerate(states):
+            c_ = s_.counters()
+            ok = (s_.status_flags() == 0 and c_["covered_pixels"] == want["covered"]
+                  and all(c_[n] == want["counters"][n] for n in ("samples", "fragments", "scanlines"))
+                  and hashlib.sha256(np.ascontiguousarray(s_.present())).hexdigest() == want["rgba8"])
+            if not ok:
+                verified = False
+                print(f"bench.py: rank {rank} context {k}: the timed frame does NOT match the oracle's digest", file=sys.stderr)
+
+    # ---- one context alone: frames back to back on one stream, and the latency of a frame the host waits for
+    n_single = max(50, min(500, args.steps * fps_step // 4))
+    for _ in range(20):
+        frame(0)
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(n_single):
+        frame(0)
+    sync()
+    single_fps = n_single / (time.perf_counter() - t1)
+    lat = []
+    for _ in range(60):
+        t1 = time.perf_counter()
+        frame(0)
+        lib.tr_synchronize(ctx)
+        lat.append(time.perf_counter() - t1)
+    latency_us = float(np.median(lat)) * 1e6
 
     # ---- per-stage GPU time with hipEvents on the library's own stream (separate loop:
     # event-bracketing every launch serialises the host, so it is not part of `value`)
@@ -194,11 +235,11 @@ def main():
     out = {
         "metric": "frames/sec at 4K (african_head 3840x2160, clear+draw+resolve)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "verified": verified,
         "vs_baseline": None, "dtype": "f64", "data": "reference assets (african_head.obj + diffuse/nm_tangent PNG), fixed frame time=1",
         "config": {"workload": f"african_head {W}x{H} single frame, 1 draw (BASELINE.json configs[2])",
-                   "frames_per_rank_per_step": 1, "contexts_per_gpu": len(states), "parallelism": f"views x{world}" if world > 1 else "single GPU"},
-        "mfragments_per_s": fps * frags / 1e6,
+                   "frames_per_rank_per_step": fps_step, "contexts_per_gpu": len(states), "parallelism": f"views x{world}" if world > 1 else "single GPU"},
+        "mfragments_per_s": fps * frags / 1e6, "single_context_fps": single_fps, "latency_us": latency_us,
         "fragments_per_frame": frags, "samples_per_frame": counters["samples"], "shaded_px_per_frame": shaded_px,
         "stages_us": stages_us,
         "roofline": {"bound": "hbm", "kernel": "k_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -209,10 +250,18 @@ def main():
         out["cpu_baseline"] = cpu_baseline(W, H, draws)
     for s_ in states:
         s_.close()
+    if world > 1:
+        v = torch.tensor([0 if verified is False else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        if verified is not None:
+            verified = bool(v.item())
+            out["verified"] = verified
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if verified is False:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

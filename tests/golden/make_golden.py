@@ -46,8 +46,36 @@ def digest(o):
             "counters": {k: o["counters"][k] for k in ("samples", "fragments", "zpass", "scanlines")}}
 
 
+def big_cases():
+    """Full-size configs[2], [3], [4] (tests/big_cases.py): hashes only.  `python tests/golden/make_golden.py --big`
+    (the 8K frame of 10.2 M triangles takes the oracle about 8 s and ~6 GB)."""
+    import big_cases as B
+
+    out = {}
+    W, H, draws = B.head_4k()
+    out["c3_head_4k"] = B.oracle_digest(oracle_ffi, W, H, draws)
+    for k in B.ORBIT_VIEWS:
+        W, H, draws = B.orbit_view(k)
+        out[f"c5_orbit_1080p_view{k}"] = B.oracle_digest(oracle_ffi, W, H, draws)
+    W, H, draws = B.diablo_1080p_frame1()
+    out["c5_diablo_1080p_frame1"] = B.oracle_digest(oracle_ffi, W, H, draws)
+    assert out["c5_diablo_1080p_frame1"]["counters"]["samples"] == 1412616  # SURVEY.md section 6
+    assert out["c5_diablo_1080p_frame1"]["covered"] == 192579
+    W, H, draws = B.head_subdivided(6, 7680, 4320)
+    out["c4_head_sub6_8k"] = B.oracle_digest(oracle_ffi, W, H, draws)
+    return out
+
+
 def main():
-    hashes = {}
+    path = os.path.join(HERE, "hashes.json")
+    if "--big" in sys.argv:  # (kept apart: the small cases take seconds, these a minute)
+        hashes = json.load(open(path))
+        hashes.update(big_cases())
+        with open(path, "w") as fh:
+            json.dump(hashes, fh, indent=1, sort_keys=True)
+        print(json.dumps({k: v for k, v in hashes.items() if k.startswith(("c3_", "c4_", "c5_"))}, indent=1))
+        return
+    hashes = {k: v for k, v in json.load(open(path)).items() if k.startswith(("c3_", "c4_", "c5_"))} if os.path.exists(path) else {}
     for name, (_, W, H, full) in CASES.items():
         o = render(name)
         hashes[name] = digest(o)
@@ -57,7 +85,7 @@ def main():
         else:  # 1/64 subsample of the big cases (every 8th pixel in x and y)
             np.savez_compressed(os.path.join(HERE, name + "_sub8.npz"), z=o["z"][::8, ::8],
                                 tri=o["seq"].astype(np.int32)[::8, ::8], rgba8=o["present"][::8, ::8])
-    with open(os.path.join(HERE, "hashes.json"), "w") as fh:
+    with open(path, "w") as fh:
         json.dump(hashes, fh, indent=1, sort_keys=True)
     print(json.dumps(hashes, indent=1))
 
