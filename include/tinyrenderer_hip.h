@@ -186,6 +186,14 @@ int tr_read_triangle_id_u32(tr_context* ctx, uint32_t* out, int layout);
 int tr_read_winner_key_u64(tr_context* ctx, uint64_t* out, int layout);
 int tr_read_rgba8(tr_context* ctx, uint8_t* out, int flip);
 int tr_read_rgba_f64(tr_context* ctx, double* out, int layout);
+/* No counterpart in the reference.  tr_read_rgba8 for callers that CANNOT allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): it never calls hipMalloc / hipFree,
+ * resolves nothing (the frame must have been resolved with TR_OUT_RGBA8: TR_ERR_INVALID otherwise) and stages
+ * the flipped image in a static device array of 3840 x 2160 pixels (33 177 600 B per GPU, held until the process
+ * ends) instead of a buffer allocated on first use; larger frames: TR_ERR_SIZE.  Pass `out` from tr_host_alloc
+ * for a copy the runtime does not stage either.  All contexts of a GPU share that array and it keeps the last
+ * call's contents (every word handed to the caller is rewritten first): calls that overlap on one GPU race. */
+int tr_read_rgba8_static(tr_context* ctx, uint8_t* out, int flip);
 /* Page-locked host memory for the read calls above (no counterpart in the reference): a device-to-host
  * copy into it runs at the link's rate instead of being staged (4K RGBA8: 0.7 ms instead of ~3 ms).
  * tr_host_alloc returns NULL on failure (or without a GPU). */

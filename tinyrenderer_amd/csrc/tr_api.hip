@@ -302,6 +302,33 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
 
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_live_contexts[kMaxDevices];  // per device (zero-initialised)
+
+// ---- tr_read_rgba8_static: the one entry point that allocates nothing.  Its staging buffer (the flipped
+// image on its way to the host, tr_read_rgba8's flip_buf) is this file-scope device array: every GPU the
+// library runs on holds its own copy (33 177 600 B) at its own address until the process ends.  The name
+// `g_static_stage` is only a host-side stand-in for it; the device address is looked up once per device
+// with that device current (tr_create) and host code uses that pointer alone.
+constexpr size_t kStaticStagePixels = (size_t)3840 * 2160;
+__device__ __align__(256) uint32_t g_static_stage[kStaticStagePixels];
+uint32_t* g_static_stage_ptr[kMaxDevices];  // per device; nullptr until tr_create ran on it
+std::mutex g_static_stage_lock;
+
+// (the caller has made `device` current)
+hipError_t init_static_stage(int device) {
+    if (device < 0 || device >= kMaxDevices) return hipSuccess;  // (the entry point reports such a device as unsupported)
+    std::lock_guard<std::mutex> g(g_static_stage_lock);
+    if (g_static_stage_ptr[device]) return hipSuccess;
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_stage));
+    if (e != hipSuccess) return e;
+    g_static_stage_ptr[device] = static_cast<uint32_t*>(p);
+    return hipSuccess;
+}
+uint32_t* static_stage(int device) {
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> g(g_static_stage_lock);
+    return g_static_stage_ptr[device];
+}
 inline std::atomic<int>& live_contexts(int device) { return g_live_contexts[device >= 0 && device < kMaxDevices ? device : 0]; }
 
 template <int PASS>
@@ -547,6 +574,7 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         return bail(TR_ERR_NO_DEVICE);
     }
     size_t npix = (size_t)width * height;
+    if (init_static_stage(device) != hipSuccess) return bail(TR_ERR_HIP);  // (device address of tr_read_rgba8_static's staging array)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->planes, 2 * npix * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
     c->depth = c->planes;
@@ -1198,6 +1226,38 @@ int tr_read_rgba8(tr_context* c, uint8_t* out, int flip) {
     }
     // (a buffer from tr_host_alloc is pinned: the copy then runs at the link's rate without staging)
     TR_HIP(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    TR_HIP(c, hipStreamSynchronize(c->stream));
+    return TR_OK;
+}
+
+// tr_read_rgba8 for callers that cannot allocate: no hipMalloc / hipFree on any path, nothing is resolved
+// (a resolve may grow buffers), the flipped image is staged in the per-device static array.
+int tr_read_rgba8_static(tr_context* c, uint8_t* out, int flip) {
+    if (!c || !out) return TR_ERR_INVALID;
+    TR_HIP(c, hipSetDevice(c->device));
+    if (!(c->resolved && (c->resolved_mask & TR_OUT_RGBA8)))
+        return fail(c, TR_ERR_INVALID, "tr_read_rgba8_static: call tr_resolve with TR_OUT_RGBA8 first (this call resolves nothing)");
+    const size_t npix = (size_t)c->W * c->H;
+    if (npix > kStaticStagePixels)
+        return fail(c, TR_ERR_SIZE, "tr_read_rgba8_static: frame larger than the static staging buffer (3840 x 2160 pixels)");
+    if (c->mode != 0) {  // tile / row raster: a pending bin-list growth (which allocates) belongs to the other read calls
+        uint32_t fl = 0;
+        TR_HIP(c, hipMemcpyAsync(&fl, c->flags, sizeof(fl), hipMemcpyDeviceToHost, c->stream));
+        TR_HIP(c, hipStreamSynchronize(c->stream));
+        if (fl & (1u << 6))
+            return fail(c, TR_ERR_UNSUPPORTED, "tr_read_rgba8_static: bin list overflow pending; tr_get_status_flags settles it (and may allocate)");
+    }
+    const uint32_t* src = c->rgba8;
+    if (flip) {
+        uint32_t* stage = static_stage(c->device);
+        if (!stage) return fail(c, TR_ERR_UNSUPPORTED, "tr_read_rgba8_static: no staging array on this device");
+        // every one of the W*H words copied below is written here first: the array's old contents
+        // (the last call's image, of any size) never reach the caller
+        hipLaunchKernelGGL(k_flip_rows, dim3(2048), dim3(256), 0, c->stream, c->rgba8, stage, c->W, c->H);
+        TR_HIP(c, hipGetLastError());
+        src = stage;
+    }
+    TR_HIP(c, hipMemcpyAsync(out, src, npix * 4, hipMemcpyDeviceToHost, c->stream));
     TR_HIP(c, hipStreamSynchronize(c->stream));
     return TR_OK;
 }
