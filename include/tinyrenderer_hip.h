@@ -55,9 +55,9 @@ enum {
     TR_FLAG_SCANLINE_OVERFLOW = 1u << 4, /* more than 2^32-1 scanlines in one frame */
     TR_FLAG_NAN_PIXEL_OVERFLOW = 1u << 5, /* more NaN-depth pixels than the side table holds
                                              (global-atomic raster mode only) */
-    TR_FLAG_BIN_OVERFLOW = 1u << 6  /* transient: the tile bin list was too small; the next call that
-                                       synchronises (reads, counters, flags) grows it and redoes the
-                                       resolve, then clears the bit */
+    TR_FLAG_BIN_OVERFLOW = 1u << 6  /* transient (tile / row raster): a bin list was too small; tr_resolve
+                                       itself grows it, redoes the resolve and clears the bit before it
+                                       returns (one host wait per resolve in those two modes) */
 };
 
 /* Raster strategies (same results, bit for bit). */
@@ -99,6 +99,10 @@ int tr_mesh_destroy(tr_context* ctx, tr_mesh* mesh);
  * flipped, i.e. row 0 is the bottom row of the decoded image (texel (x,y) = nd_img[[x,y,:]]). */
 int tr_texture_create(tr_context* ctx, const uint8_t* rgba8, int width, int height,
                       tr_texture** out_tex);
+/* Lifetime: the draws recorded since tr_clear refer to their textures until the next tr_clear.  Destroying one
+ * through the context that drew with it is safe: what that frame has resolved stays readable, a further resolve
+ * of the frame (more draws, or a plane not asked for before) fails with TR_ERR_INVALID.  A texture drawn with on
+ * ANOTHER context of the same device must outlive that context's frame (tr_clear or tr_destroy first). */
 int tr_texture_destroy(tr_context* ctx, tr_texture* tex);
 
 /* The reference's shader pair (src/main.rs:146-267) as data. */
@@ -206,6 +210,22 @@ void tr_host_free(void* p);
  * [2] scanlines are not counted by TR_RASTER_TILE (0 there); [5..7] reserved. */
 int tr_get_counters(tr_context* ctx, uint64_t out[8]);
 int tr_get_status_flags(tr_context* ctx, uint32_t* out_flags);
+
+/* Batched views.  The reference renders one view per iteration of its loop -- clear_screen, camera, then
+ * render_mesh_component per mesh (src/main.rs:57-116,272-273).  tr_render_views is n_views such iterations over
+ * ONE mesh in one call: params[v] is what tr_draw takes for view v (its pmv, normal matrix, camera position as the
+ * light, textures).  It begins a new frame (an implicit tr_clear), renders every view into its own W x H slice of
+ * the planes -- one setup launch over (view, triangle), one depth pass, one winner pass, one shade launch for the
+ * whole batch -- and resolves with out_mask (TR_OUT_*).  Per view the results are those of tr_clear + tr_draw +
+ * tr_resolve on a W x H context, except that a winner key's / triangle id's tri_seq counts over the batch:
+ * view v's triangle k is v * n_triangles + k.  tr_select_view picks the slice the tr_read_* calls,
+ * tr_read_rgba8_static and tr_device_ptr_rgba8 refer to (view 0 after tr_create_views); the slices are contiguous
+ * in view order, so tr_device_ptr_rgba8 of view 0 addresses all n_views images.  tr_get_counters sums over the
+ * batch.  A context made by tr_create_views (max_views in [2, 4096], W * H * max_views < 2^31) renders through
+ * tr_render_views only (tr_draw: TR_ERR_INVALID) and uses the global raster; no bands, no extension shaders. */
+int tr_create_views(int device, int width, int height, int max_views, tr_context** out_ctx);
+int tr_render_views(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask);
+int tr_select_view(tr_context* ctx, int view);
 
 /* Multi-GPU band sharding (no reference analogue; exact because a pixel's result is a pure min
  * over the samples landing on it): restrict this context to pixel rows [y_lo, y_hi), whole

@@ -521,6 +521,72 @@ def test_row_raster_grows_its_buffers(oracle, monkeypatch):
             monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("mode,env", [(2, {"TR_ROW_REFS": "500"}), (2, {"TR_SCAN_RECORDS": "1000"}), (1, {"TR_TILE_PAIRS": "300"})])
+def test_bin_overflow_is_settled_by_resolve_itself(oracle, monkeypatch, mode, env):
+    """A GPU-resident loop never reads back: tr_resolve, consume tr_device_ptr_rgba8 on the stream, tr_clear.
+    A bin list that overflows (tile / row raster) must therefore be grown and the frame redone inside
+    tr_resolve, and nothing of the aborted attempt may reach the next, smaller frame."""
+    import ctypes as C
+
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, Hh = 400, 300
+    hip = C.CDLL("libamdhip64.so.7")
+    lib = _ffi.load()
+    big = _head_scene(W, Hh, with_eye=True)
+    eye_mc = SU.component("eye_inner")
+    small = [(eye_mc, scenes.shader_for(eye_mc, W, Hh, eye=(0.3, 0.1, 1.2)))]
+    st = ModelRendererState(W, Hh, raster_mode=mode)
+    try:
+        for draws in (big, small, big):
+            clear_screen(st)
+            for d in draws:
+                render_mesh_component(st, *d)
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            st.synchronize()
+            # the device plane as a consumer on the stream would see it: no library read in between
+            dev = C.c_void_p()
+            assert lib.tr_device_ptr_rgba8(st._ctx, C.byref(dev)) == 0
+            got = np.empty((Hh, W, 4), dtype=np.uint8)
+            assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), dev, C.c_size_t(got.nbytes), 2) == 0  # device to host
+            want = SU.oracle_render(oracle, W, Hh, draws)["present"][::-1]  # (the plane is not flipped)
+            assert np.array_equal(got, want)
+        assert st.status_flags() == 0
+    finally:
+        st.close()
+
+
+def test_texture_destroyed_under_a_recorded_frame(oracle):
+    """Advisor finding, round 1: tr_texture_destroy freed memory the frame's recorded draws still pointed at, and a
+    late plane request shaded through it.  Now: what is resolved stays readable, a further resolve is refused,
+    the next frame is unaffected."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 160, 120
+    draws = _head_scene(W, Hh)
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    st = ModelRendererState(W, Hh)
+    try:
+        clear_screen(st)
+        render_mesh_component(st, *draws[0])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        tex = st._textures.pop(id(draws[0][0].texture))
+        assert st._lib.tr_texture_destroy(st._ctx, tex) == 0
+        assert np.array_equal(st.present(), o["present"])       # resolved: still there
+        with pytest.raises(_ffi.TrError, match="destroyed"):
+            st.z_buffer                                          # would shade again through the freed texture
+        clear_screen(st)                                         # a new frame (the texture is uploaded again)
+        render_mesh_component(st, *draws[0])
+        assert np.array_equal(st.z_buffer[..., 0].view(np.uint64), o["z"].view(np.uint64))
+        assert np.array_equal(st.present(), o["present"])
+    finally:
+        st.close()
+
+
 def test_small_triangle_path(oracle, monkeypatch):
     """k_small (one thread per triangle half, taken by triangles of at most 9 scanlines per half in
     draws of 65 536 triangles or more): forced onto every draw here.  Whole frames, counters, bands,

@@ -209,3 +209,21 @@ def test_drawable_z_buffer():
     """helpers::get_drawable_z_buffer (src/helpers/mod.rs:336-350)."""
     z = np.array([[-np.inf, -1.0, 0.0], [0.5, 4.0, np.nan]])
     assert np.array_equal(H.get_drawable_z_buffer(z), np.array([[0.0, 0.0, 0.0], [2.0, 0.25, 0.0]]))
+
+
+def test_obj_numbers_of_any_length_polygons_of_any_size_and_bad_corners():
+    """Advisor findings, round 1: a numeric token of 64+ characters was cut and its tail read as the next
+    coordinate; polygons beyond 64 corners were truncated; numbers followed the process locale."""
+    from tinyrenderer_amd import helpers as H
+
+    long_num = "0." + "1234567890" * 9  # 92 characters
+    n = 100
+    verts = "".join(f"v {float(np.cos(2 * np.pi * k / n))!r} {float(np.sin(2 * np.pi * k / n))!r} 0\n" for k in range(n))
+    text = f"v {long_num} +2.5 -1e400\nv 1e-400 -0.0 1E2\n" + verts + "f " + " ".join(str(k + 3) for k in range(n)) + "\n"
+    obj = H.parse_obj_native(text)
+    assert obj.vertices[0].tolist() == [float(long_num), 2.5, float("-inf")]
+    assert obj.vertices[1].tolist() == [0.0, 0.0, 100.0] and np.signbit(obj.vertices[1][1])
+    assert obj.triangles.shape[0] == n - 2 and obj.triangles[-1].tolist()[::3] == [2, n, n + 1]
+    for bad in ("v 1 2 3\nv 0 0 0\nv 1 1 1\nf 1 2 x3\n", "v 1,5 2 3\n"):
+        with pytest.raises(Exception):
+            H.parse_obj_native(bad)

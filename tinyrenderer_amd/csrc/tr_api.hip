@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -53,6 +54,17 @@ struct tr_context {
     int device = 0;
     int W = 0, H = 0;
     int y_lo = 0, y_hi = 0;
+    // batched views (tr_create_views / tr_render_views): the planes hold max_views slices of W x H pixels
+    int max_views = 1;
+    int n_views = 1;                 // slices the current frame covers (1 unless the frame is a tr_render_views batch)
+    int sel_view = 0;                // slice the tr_read_* calls and tr_device_ptr_rgba8 refer to (tr_select_view)
+    uint32_t view_tris = 0;          // triangles per view of the current batch (0: the frame is not a batch)
+    size_t npix_all = 0;             // W * H * max_views
+    uint32_t blk_per_view = 0, blk_rows_per_view = 0;
+    ViewDev* view_table = nullptr;   // device, max_views entries
+    ViewDev* view_stage[2] = {nullptr, nullptr};  // page-locked host copies, used in turn
+    hipEvent_t view_ev[2] = {nullptr, nullptr};   // "the upload from view_stage[i] has completed"
+    int view_turn = 0;
     hipStream_t stream = nullptr;
     unsigned long long* planes = nullptr;  // depth[W*H] then wkey[W*H]
     unsigned long long* depth = nullptr;
@@ -93,6 +105,7 @@ struct tr_context {
     uint32_t n_bins_padded = 0;
     uint32_t ref_cap = 2u << 20;
     int nseg = 0;
+    bool bin_dirty = false;          // row raster: a resolve ended with its overflow unsettled (fill cursors left behind)
     uint8_t* blk_flags = nullptr;    // per shade block [2 b]: touched this frame, [2 b + 1]: rgba8 not background
     uint32_t n_blk = 0;
     int blocks_x = 0;
@@ -107,6 +120,8 @@ struct tr_context {
     DrawDev* draw_table = nullptr;
     DrawExt* ext_table = nullptr;    // extension shaders: allocated with the first tr_draw_ext that names one
     std::vector<tr_shadow_map*> frame_maps;  // shadow maps the draws since tr_clear refer to
+    std::vector<const tr_texture*> frame_textures;  // textures the draws since tr_clear refer to
+    bool frame_lost_texture = false; // one of them was destroyed: the frame cannot be shaded again
     bool frame_has_ext = false;      // some draw since tr_clear uses an extension: k_shade<true>
     DrawDev draw0;                   // host copy of the frame's first draw (a kernel argument of the shade pass)
     uint32_t draw_cap = 4096;
@@ -154,16 +169,24 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour);
 namespace {
 
 int fail(tr_context* c, int code, const std::string& msg) {
-    if (c) c->err = msg;
+    if (c) {
+        try { c->err = msg; }
+        catch (...) { c->err.clear(); }  // (nothing may unwind through the C boundary)
+    }
     return code;
+}
+
+int fail_hip(tr_context* c, hipError_t e, const char* what) {
+    const int code = e == hipErrorOutOfMemory ? TR_ERR_OOM : TR_ERR_HIP;
+    try { return fail(c, code, std::string(what) + ": " + hipGetErrorString(e)); }
+    catch (...) { return code; }
 }
 
 #define TR_HIP(c, expr)                                                                         \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess)                                                                   \
-            return fail(c, e_ == hipErrorOutOfMemory ? TR_ERR_OOM : TR_ERR_HIP,                 \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+            return fail_hip(c, e_, #expr);                                                      \
     } while (0)
 
 struct ProfScope {
@@ -295,9 +318,74 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.clean_state = nullptr;
     ra.clean_words = 0;
     ra.clean_nan = nullptr;
+    ra.view_tris = c->view_tris;
+    ra.view_pix = (uint32_t)((size_t)c->W * c->H);
+    ra.view_blk = c->blk_per_view;
     ra.debug = 0;
     ra.trace = nullptr;
     ra.trace_cap = 0;
+}
+
+// The fragment constants of one draw (src/main.rs:173-267) from its tr_draw_params.
+void fill_draw_dev(DrawDev& d, const tr_draw_params* p) {
+    std::memset(&d, 0, sizeof(d));
+    d.tex = p->diffuse ? p->diffuse->dev : nullptr;
+    d.tw = p->diffuse ? p->diffuse->w : 0;
+    d.th = p->diffuse ? p->diffuse->h : 0;
+    d.nm = p->normal_map ? p->normal_map->dev : nullptr;
+    d.nw = p->normal_map ? p->normal_map->w : 0;
+    d.nh = p->normal_map ? p->normal_map->h : 0;
+    // src/main.rs:249-251: Vector3::new(camera_pos).normalize(); norm^2 = (x*x + y*y) + z*z
+    {
+        double x = p->light_dir[0], y = p->light_dir[1], z = p->light_dir[2];
+        double n = std::sqrt(0.0 + ((x * x + y * y) + z * z));
+        d.light[0] = x / n; d.light[1] = y / n; d.light[2] = z / n;
+    }
+    d.ambient = p->ambient;
+    d.intensity = p->intensity;
+    for (int i = 0; i < 4; ++i) d.vcol[i] = p->vertex_color[i];
+    d.use_nm = p->use_normal_map && p->normal_map;
+}
+
+// src/model_renderer/mod.rs:314-318: scale((W-1)/2,(H-1)/2,1) * translate(1,1,0)
+Mat4 viewport_matrix(int W, int H) {
+    Mat4 sc = {{(double)(W - 1) / 2.0, 0, 0, 0, 0, (double)(H - 1) / 2.0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
+    Mat4 trn = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1.0, 1.0, 0.0, 1}};
+    return host_mat4_mul(sc, trn);
+}
+
+// The scanline prefix of halves [lo, lo + n_halves), continuing from the previous draw's total.
+int launch_scan(tr_context* c, uint32_t lo, uint32_t n_halves) {
+    uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
+    if (tiles <= 8) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
+                           c->half_off + lo, c->flags);
+    } else {
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo,
+                           n_halves, c->tile_sum);
+        hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(kScanThreads), 0, c->stream, c->tile_sum, tiles,
+                           c->half_off + lo, c->flags);
+        hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
+                           c->half_off + lo, (const unsigned long long*)c->tile_sum, c->flags);
+    }
+    TR_HIP(c, hipGetLastError());
+    return TR_OK;
+}
+
+// Records of the frame's first slots: a triangle of a few pixels takes 6-8 slots; slots beyond the buffer cost a
+// rebuild per pass.  Grown with the first draw of a frame unless TR_SCAN_RECORDS pins the size.
+int grow_records_for(tr_context* c, uint64_t n_tris) {
+    if (!(c->tri_total == 0 && c->rec_auto && c->mode != 1)) return TR_OK;
+    uint64_t want = 8ull * n_tris;
+    if (want > (64ull << 20)) want = 64ull << 20;  // 4 GB of records at most
+    if (want > c->rec_cap) {
+        TR_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->rec);
+        c->rec = nullptr;
+        TR_HIP(c, hipMalloc(&c->rec, want * sizeof(ScanRec)));
+        c->rec_cap = (uint32_t)want;
+    }
+    return TR_OK;
 }
 
 constexpr int kMaxDevices = 64;
@@ -333,6 +421,11 @@ inline std::atomic<int>& live_contexts(int device) { return g_live_contexts[devi
 
 template <int PASS>
 void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block, hipStream_t stream, const RasterArgs& ra) {
+    if (ra.view_tris) {  // a batch of views: the tuned settings only (filter in front of the depth atomics, none in front of the winner's)
+        if (threads == 128) hipLaunchKernelGGL((k_raster<PASS, PASS == 0, false, 128, true>), grid, block, 0, stream, ra);
+        else hipLaunchKernelGGL((k_raster<PASS, PASS == 0, false, 256, true>), grid, block, 0, stream, ra);
+        return;
+    }
 #define TR_LAUNCH(PC, DB, TH) hipLaunchKernelGGL((k_raster<PASS, PC, DB, TH>), grid, block, 0, stream, ra)
     if (threads == 128) {
         if (dbg) { if (precheck) TR_LAUNCH(true, true, 128); else TR_LAUNCH(false, true, 128); }
@@ -450,11 +543,11 @@ int settle_row_overflow(tr_context* c) {
             c->depth_upto = 0;
             c->counted_upto = 0;
             c->wkey_dirty = false;
-            TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * (size_t)c->W * c->H * sizeof(unsigned long long), c->stream));
+            TR_HIP(c, hipMemsetAsync(c->planes, 0xFF, 2 * c->npix_all * sizeof(unsigned long long), c->stream));
             TR_HIP(c, hipMemset2DAsync(c->blk_flags, 2, 0, 1, c->n_blk, c->stream));
             // k_clear_state's job for the NaN table was done at tr_clear; the row raster never touched it
         }
-        int rc = tr_resolve(c, mask);
+        int rc = resolve_frame(c, mask, true);
         if (rc != TR_OK) return rc;
         if (fallback) return TR_OK;
     }
@@ -462,7 +555,11 @@ int settle_row_overflow(tr_context* c) {
 }
 
 int settle_bin_overflow(tr_context* c) {
-    if (c->mode == 2 && c->resolved) return settle_row_overflow(c);
+    if (c->mode == 2 && c->resolved) {
+        const int rc = settle_row_overflow(c);
+        c->bin_dirty = rc != TR_OK;
+        return rc;
+    }
     if (c->mode != 1 || !c->resolved) return TR_OK;
     for (int attempt = 0; attempt < 4; ++attempt) {
         uint32_t fl = 0;
@@ -483,7 +580,7 @@ int settle_bin_overflow(tr_context* c) {
         c->resolved = false;
         // the fragment counter was bumped by the aborted attempt
         TR_HIP(c, hipMemsetAsync(c->counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
-        int rc = tr_resolve(c, mask);
+        int rc = resolve_frame(c, mask, true);
         if (rc != TR_OK) return rc;
     }
     return fail(c, TR_ERR_UNSUPPORTED, "tile bin list kept overflowing");
@@ -501,14 +598,16 @@ int need_plane(tr_context* c, uint32_t plane, bool colour = true) {
 template <typename T>
 int read_plane(tr_context* c, const T* dev, T* out, int layout, int comps) {
     size_t npix = (size_t)c->W * c->H;
+    dev += (size_t)c->sel_view * npix * comps;  // (tr_select_view; slice 0 of an ordinary context)
     if (layout == TR_LAYOUT_ROW_MAJOR) {
         TR_HIP(c, hipMemcpyAsync(out, dev, npix * comps * sizeof(T), hipMemcpyDeviceToHost, c->stream));
         TR_HIP(c, hipStreamSynchronize(c->stream));
         return TR_OK;
     }
     if (layout != TR_LAYOUT_REFERENCE) return fail(c, TR_ERR_INVALID, "unknown layout");
-    std::vector<T> tmp(npix * comps);
-    TR_HIP(c, hipMemcpyAsync(tmp.data(), dev, npix * comps * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    std::unique_ptr<T[]> tmp(new (std::nothrow) T[npix * comps]);
+    if (!tmp) return fail(c, TR_ERR_OOM, "host staging buffer for the reference layout");
+    TR_HIP(c, hipMemcpyAsync(tmp.get(), dev, npix * comps * sizeof(T), hipMemcpyDeviceToHost, c->stream));
     TR_HIP(c, hipStreamSynchronize(c->stream));
     for (int y = 0; y < c->H; ++y)
         for (int x = 0; x < c->W; ++x)
@@ -526,10 +625,14 @@ const char* tr_version(void) { return "tinyrenderer_hip abi=4 arch=gfx950 fp=f64
 
 const char* tr_last_error(const tr_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int tr_create(int device, int width, int height, tr_context** out_ctx) {
+int tr_create(int device, int width, int height, tr_context** out_ctx) { return tr_create_views(device, width, height, 1, out_ctx); }
+
+int tr_create_views(int device, int width, int height, int max_views, tr_context** out_ctx) {
     if (!out_ctx) return TR_ERR_INVALID;
     *out_ctx = nullptr;
     if (width < 1 || height < 1 || (int64_t)width * height > (int64_t)1 << 30) return TR_ERR_SIZE;
+    // (pixel indices over all slices are 32-bit in the kernels; a batch's views are draws of one frame: at most 4096)
+    if (max_views < 1 || max_views > 4096 || (int64_t)width * height * max_views >= (int64_t)1 << 31) return TR_ERR_SIZE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
         return TR_ERR_NO_DEVICE;
@@ -540,6 +643,9 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     c->H = height;
     c->y_lo = 0;
     c->y_hi = height;
+    c->max_views = max_views;
+    c->n_views = max_views;  // (an empty frame resolves every slice)
+    c->npix_all = (size_t)width * height * (size_t)max_views;
     if (const char* e = std::getenv("TR_RASTER_MODE"))
         c->mode = (std::strcmp(e, "tile") == 0 || std::strcmp(e, "1") == 0) ? 1
                   : (std::strcmp(e, "rows") == 0 || std::strcmp(e, "2") == 0) ? 2 : 0;
@@ -561,6 +667,7 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     }
     if (const char* e = std::getenv("TR_ROW_REFS")) c->ref_cap = (uint32_t)std::strtoul(e, nullptr, 10);
     if (c->ref_cap < 1) c->ref_cap = 1;
+    if (max_views > 1) c->mode = 0;  // (batches of views exist in the global raster only)
     auto bail = [&](int code) {
         tr_destroy(c);
         return code;
@@ -576,10 +683,18 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     size_t npix = (size_t)width * height;
     if (init_static_stage(device) != hipSuccess) return bail(TR_ERR_HIP);  // (device address of tr_read_rgba8_static's staging array)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(TR_ERR_HIP);
-    if (hipMalloc(&c->planes, 2 * npix * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipMalloc(&c->planes, 2 * c->npix_all * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
     c->depth = c->planes;
-    c->wkey = c->planes + npix;
-    if (hipMalloc(&c->rgba8, npix * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+    c->wkey = c->planes + c->npix_all;
+    if (hipMalloc(&c->rgba8, c->npix_all * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
+    if (max_views > 1) {
+        if (hipMalloc(&c->view_table, (size_t)max_views * sizeof(ViewDev)) != hipSuccess) return bail(TR_ERR_OOM);
+        for (int i = 0; i < 2; ++i) {
+            if (hipHostMalloc((void**)&c->view_stage[i], (size_t)max_views * sizeof(ViewDev), hipHostMallocDefault) != hipSuccess) return bail(TR_ERR_OOM);
+            if (hipEventCreateWithFlags(&c->view_ev[i], hipEventDisableTiming) != hipSuccess) return bail(TR_ERR_HIP);
+        }
+    }
+    (void)npix;
     if (hipMalloc(&c->draw_table, c->draw_cap * sizeof(DrawDev)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMalloc(&c->state_both, 2 * (size_t)kStateWords * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMalloc(&c->nan_both, 2 * sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
@@ -591,6 +706,8 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
         const size_t quantum = 4 * (size_t)kTileScanThreads;
         c->n_tiles_padded = (uint32_t)((n_tiles + quantum - 1) / quantum * quantum);
         c->pair_cap = 4u << 20;
+        if (const char* e = std::getenv("TR_TILE_PAIRS")) c->pair_cap = (uint32_t)std::strtoul(e, nullptr, 10);  // (tests: force a growth)
+        if (c->pair_cap < 1) c->pair_cap = 1;
         if (hipMalloc(&c->tile_cnt, c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMalloc(&c->tile_off, ((size_t)c->n_tiles_padded + 4) * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMalloc(&c->tile_list, (size_t)c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
@@ -611,7 +728,9 @@ int tr_create(int device, int width, int height, tr_context** out_ctx) {
     }
     if (const char* e = std::getenv("TR_SHADE_SKIP_CLEAN")) c->skip_clean = std::atoi(e) != 0;
     c->blocks_x = (width + kShadeBW - 1) / kShadeBW;
-    c->n_blk = (uint32_t)c->blocks_x * (uint32_t)((height + kShadeBH - 1) / kShadeBH);
+    c->blk_rows_per_view = (uint32_t)((height + kShadeBH - 1) / kShadeBH);
+    c->blk_per_view = (uint32_t)c->blocks_x * c->blk_rows_per_view;
+    c->n_blk = c->blk_per_view * (uint32_t)max_views;
     if (hipMalloc(&c->blk_flags, 2 * (size_t)c->n_blk + 8) != hipSuccess)  // (read as aligned dwords)
         return bail(TR_ERR_OOM);
     // every block starts "painted": the first resolve writes the whole frame
@@ -642,6 +761,11 @@ void tr_destroy(tr_context* c) {
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
+    (void)hipFree(c->view_table);
+    for (int i = 0; i < 2; ++i) {
+        if (c->view_stage[i]) (void)hipHostFree(c->view_stage[i]);
+        if (c->view_ev[i]) (void)hipEventDestroy(c->view_ev[i]);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -652,7 +776,7 @@ int tr_clear(tr_context* c) {
     if (!c) return TR_ERR_INVALID;
     TR_HIP(c, hipSetDevice(c->device));
     ProfScope ps(c, ST_CLEAR);
-    size_t npix = (size_t)c->W * c->H;
+    size_t npix = c->npix_all;
     {   // counters, covered-pixel counters, status flags, NaN table: the other half of the state,
         // which the last shade pass has already zeroed unless no resolve happened since the last clear
         const int other = 1 - c->state_idx;
@@ -664,6 +788,12 @@ int tr_clear(tr_context* c) {
         }
         use_state(c, other);
         c->other_state_clean = false;
+    }
+    if (c->mode == 2 && c->bin_dirty) {
+        // row raster: the raster zeroes the fill cursors of the bins it consumes; a resolve that gave up on an
+        // overflow (it could not grow its lists) leaves them behind
+        TR_HIP(c, hipMemsetAsync(c->bin_cnt, 0, (size_t)c->n_bins_padded * sizeof(uint32_t), c->stream));
+        c->bin_dirty = false;
     }
     if (c->mode == 1) {
         // tile raster: no plane is cleared; every non-empty tile is rewritten, empty ones are never read
@@ -686,7 +816,11 @@ int tr_clear(tr_context* c) {
     c->resolved_mask = 0;
     c->frame_has_ext = false;
     c->frame_maps.clear();
+    c->frame_textures.clear();
+    c->frame_lost_texture = false;
     c->small_any = false;
+    c->view_tris = 0;
+    c->n_views = c->max_views;  // (an empty frame resolves every slice)
     return TR_OK;
 }
 
@@ -697,9 +831,11 @@ int tr_mesh_create(tr_context* c, const double* positions, int64_t n_positions, 
     *out_mesh = nullptr;
     if (n_positions < 0 || n_normals < 0 || n_uvw < 0 || n_triangles < 0)
         return fail(c, TR_ERR_INVALID, "negative count");
-    if (n_triangles > (int64_t)kTriSeqMax || n_positions > (int64_t)1 << 30 || n_normals > (int64_t)1 << 30 ||
-        n_uvw > (int64_t)1 << 30)
-        return fail(c, TR_ERR_SIZE, "mesh too large");
+    // (what the kernels can index: positions + normals are one launch of 32-bit thread ids, 3 * index + 2 and
+    // 2 * n + index are formed in 64 bits; 2^28 - 1 triangles is the winner key's field)
+    constexpr int64_t kAttrMax = (int64_t)1 << 28;
+    if (n_triangles > (int64_t)kTriSeqMax || n_positions > kAttrMax || n_normals > kAttrMax || n_uvw > kAttrMax)
+        return fail(c, TR_ERR_SIZE, "mesh too large: at most 2^28 positions / normals / texture vertices and 2^28 - 1 triangles");
     if ((n_positions && !positions) || (n_normals && !normals) || (n_uvw && !uvw) || (n_triangles && !idx))
         return fail(c, TR_ERR_INVALID, "null array");
     bool any_uv = false;
@@ -772,6 +908,9 @@ int tr_texture_destroy(tr_context* c, tr_texture* t) {
     if (!t) return TR_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    // The draws recorded since tr_clear keep the texture's device address; a later plane request on this frame
+    // would shade through it again.  What is resolved stays readable; any further resolve of this frame is refused.
+    if (std::find(c->frame_textures.begin(), c->frame_textures.end(), t) != c->frame_textures.end()) c->frame_lost_texture = true;
     (void)hipFree(t->dev);
     delete t;
     return TR_OK;
@@ -798,6 +937,7 @@ static int shadow_snapshot(tr_context* light, tr_shadow_map* m) {
 int tr_shadow_map_create(tr_context* light, tr_shadow_map** out) {
     if (!light || !out) return TR_ERR_INVALID;
     *out = nullptr;
+    if (light->max_views > 1) return fail(light, TR_ERR_UNSUPPORTED, "no shadow maps from a tr_create_views context");
     TR_HIP(light, hipSetDevice(light->device));
     tr_shadow_map* m = new (std::nothrow) tr_shadow_map();
     if (!m) return fail(light, TR_ERR_OOM, "shadow map");
@@ -836,6 +976,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     if (!c || !mesh || !p) return TR_ERR_INVALID;
     if (mesh->any_uv && (!p->diffuse || (p->use_normal_map && !p->normal_map)))
         return fail(c, TR_ERR_INVALID, "mesh has texture coordinates but a texture is missing");
+    if (c->max_views > 1) return fail(c, TR_ERR_INVALID, "a context made by tr_create_views renders through tr_render_views only");
     if (c->draw_count >= c->draw_cap) return fail(c, TR_ERR_SIZE, "more than 4096 draws since tr_clear");
     if ((uint64_t)c->tri_total + (uint64_t)mesh->n_tris > (uint64_t)kTriSeqMax)
         return fail(c, TR_ERR_SIZE, "more than 2^28-1 triangles since tr_clear");
@@ -846,6 +987,11 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         if (x->model < TR_SHADE_REFERENCE || x->model > TR_SHADE_PHONG) return fail(c, TR_ERR_INVALID, "unknown shading model");
         if (x->shadow && x->shadow->device != c->device) return fail(c, TR_ERR_INVALID, "shadow map lives on another device");
     }
+    for (const tr_texture* t : {p->diffuse, p->normal_map, x ? x->specular_map : nullptr})
+        if (t && std::find(c->frame_textures.begin(), c->frame_textures.end(), t) == c->frame_textures.end()) {
+            try { c->frame_textures.push_back(t); }
+            catch (...) { return fail(c, TR_ERR_OOM, "texture list"); }
+        }
     const bool ext_draw = x && (x->model != TR_SHADE_REFERENCE || x->shadow);
     if (ext_draw || c->ext_table) {
         // (once the table exists every draw writes its entry: a frame may mix both kinds)
@@ -861,7 +1007,10 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
             if (x->shadow) {
                 e.shadow = x->shadow->dev; e.mw = x->shadow->w; e.mh = x->shadow->h;
                 tr_shadow_map* sm = const_cast<tr_shadow_map*>(x->shadow);
-                if (std::find(c->frame_maps.begin(), c->frame_maps.end(), sm) == c->frame_maps.end()) c->frame_maps.push_back(sm);
+                if (std::find(c->frame_maps.begin(), c->frame_maps.end(), sm) == c->frame_maps.end()) {
+                    try { c->frame_maps.push_back(sm); }
+                    catch (...) { return fail(c, TR_ERR_OOM, "shadow map list"); }
+                }
             }
             e.shininess = x->shininess; e.strength = x->specular_strength;
             e.bias = x->shadow_bias; e.dim = x->shadow_dim;
@@ -877,18 +1026,8 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     }
     int rc = ensure_tri_capacity(c, (size_t)c->tri_total + (size_t)mesh->n_tris);
     if (rc != TR_OK) return rc;
-    if (c->tri_total == 0 && c->rec_auto && c->mode != 1) {
-        // a triangle of a few pixels takes 6-8 slots; records beyond the buffer cost a rebuild per pass
-        uint64_t want = 8ull * (uint64_t)mesh->n_tris;
-        if (want > (64ull << 20)) want = 64ull << 20;  // 4 GB of records at most
-        if (want > c->rec_cap) {
-            TR_HIP(c, hipStreamSynchronize(c->stream));
-            (void)hipFree(c->rec);
-            c->rec = nullptr;
-            TR_HIP(c, hipMalloc(&c->rec, want * sizeof(ScanRec)));
-            c->rec_cap = (uint32_t)want;
-        }
-    }
+    rc = grow_records_for(c, (uint64_t)mesh->n_tris);
+    if (rc != TR_OK) return rc;
     rc = ensure_scratch(c, &c->ndc, &c->ndc_cap, (size_t)mesh->n_pos * 3);
     if (rc != TR_OK) return rc;
     rc = ensure_scratch(c, &c->nout, &c->nout_cap, (size_t)(mesh->n_nrm ? mesh->n_nrm : 1) * 3);
@@ -901,8 +1040,8 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     const bool fused = c->fused_front && c->mode != 1 && (uint64_t)mesh->n_tris <= 16384u;  // (at most 256 workgroups, of 64 threads at the least: k_setup<true>)
     if (!fused) {
         ProfScope ps(c, ST_TRANSFORM);
-        int n = (int)(mesh->n_pos + mesh->n_nrm);
-        hipLaunchKernelGGL(k_transform, dim3((n + 255) / 256), dim3(256), 0, c->stream, mesh->pos, (int)mesh->n_pos,
+        const int64_t n = mesh->n_pos + mesh->n_nrm;  // (<= 2^29: tr_mesh_create)
+        hipLaunchKernelGGL(k_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mesh->pos, (int)mesh->n_pos,
                            mesh->nrm, (int)mesh->n_nrm, pmv, nmat, c->ndc, c->nout);
         TR_HIP(c, hipGetLastError());
     }
@@ -914,10 +1053,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.idx = mesh->idx; sa.pos = mesh->pos; sa.uvw = mesh->uvw; sa.ndc = c->ndc; sa.nout = c->nout;
         sa.n_pos = (int)mesh->n_pos; sa.n_nrm = (int)mesh->n_nrm; sa.n_tris = (int)mesh->n_tris;
         sa.tri_base = tri_base; sa.draw = c->draw_count; sa.W = c->W; sa.H = c->H;
-        // src/model_renderer/mod.rs:314-318: scale((W-1)/2,(H-1)/2,1) * translate(1,1,0)
-        Mat4 sc = {{(double)(c->W - 1) / 2.0, 0, 0, 0, 0, (double)(c->H - 1) / 2.0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}};
-        Mat4 trn = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1.0, 1.0, 0.0, 1}};
-        sa.vpm = host_mat4_mul(sc, trn);
+        sa.vpm = viewport_matrix(c->W, c->H);
         sa.nmat = nmat;
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
@@ -930,29 +1066,14 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
             c->small_any = true;
         }
         DrawDev& d = sa.params;
-        std::memset(&d, 0, sizeof(d));
-        d.tex = p->diffuse ? p->diffuse->dev : nullptr;
-        d.tw = p->diffuse ? p->diffuse->w : 0;
-        d.th = p->diffuse ? p->diffuse->h : 0;
-        d.nm = p->normal_map ? p->normal_map->dev : nullptr;
-        d.nw = p->normal_map ? p->normal_map->w : 0;
-        d.nh = p->normal_map ? p->normal_map->h : 0;
-        // src/main.rs:249-251: Vector3::new(camera_pos).normalize(); norm^2 = (x*x + y*y) + z*z
-        {
-            double x = p->light_dir[0], y = p->light_dir[1], z = p->light_dir[2];
-            double n = std::sqrt(0.0 + ((x * x + y * y) + z * z));
-            d.light[0] = x / n; d.light[1] = y / n; d.light[2] = z / n;
-        }
-        d.ambient = p->ambient;
-        d.intensity = p->intensity;
-        for (int i = 0; i < 4; ++i) d.vcol[i] = p->vertex_color[i];
-        d.use_nm = p->use_normal_map && p->normal_map;
+        fill_draw_dev(d, p);
         sa.draw_table = c->draw_table;
         if (c->draw_count == 0) c->draw0 = d;
         sa.nrm = mesh->nrm; sa.pmv = pmv; sa.ticket = c->ticket; sa.half_off = c->half_off;
         if (++c->scan_tag == 0) c->scan_tag = 1;
         sa.scan_tag = c->scan_tag;
         sa.scan_lo = 2u * tri_base; sa.n_halves = n_halves;
+        sa.views = nullptr; sa.n_views = 0;
         if (fused) {
             // (measured: 128 threads per workgroup; 64 / 256 cost the orbit rehearsal 1 % / 4 % with four contexts)
             static const int st = std::getenv("TR_SETUP_THREADS") ? std::atoi(std::getenv("TR_SETUP_THREADS")) : 128;
@@ -963,20 +1084,8 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         TR_HIP(c, hipGetLastError());
         if (c->mode != 1 && !fused) {
             // prefix of scanline counts, continuing from the previous draw's total
-            const uint32_t lo = 2u * tri_base;
-            uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
-            if (tiles <= 8) {
-                hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
-                                   c->half_off + lo, c->flags);
-            } else {
-                hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo,
-                                   n_halves, c->tile_sum);
-                hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(kScanThreads), 0, c->stream, c->tile_sum, tiles,
-                                   c->half_off + lo, c->flags);
-                hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
-                                   c->half_off + lo, (const unsigned long long*)c->tile_sum, c->flags);
-            }
-            TR_HIP(c, hipGetLastError());
+            rc = launch_scan(c, 2u * tri_base, n_halves);
+            if (rc != TR_OK) return rc;
         }
     }
     c->keys_valid = false;
@@ -1002,15 +1111,121 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     return TR_OK;
 }
 
-int tr_resolve(tr_context* c, uint32_t out_mask) { return resolve_frame(c, out_mask, true); }
+// Tile and row raster: a bin list that proved too small is grown and the resolve redone HERE (one read of the
+// status word, i.e. a host wait per resolve in those two modes), so that what tr_resolve leaves in the planes
+// is the frame -- a caller that consumes tr_device_ptr_rgba8 on the stream and clears without ever reading back
+// would otherwise get a frame that drew nothing, and the aborted frame's fill cursors would leak into the next.
+int tr_select_view(tr_context* c, int view) {
+    if (!c) return TR_ERR_INVALID;
+    if (view < 0 || view >= c->n_views) return fail(c, TR_ERR_INVALID, "tr_select_view: no such view in the current frame");
+    c->sel_view = view;
+    return TR_OK;
+}
+
+// The reference renders one view per iteration of its loop (src/main.rs:57-116,272-273: clear_screen, camera,
+// render_mesh_component).  Here n_views iterations over ONE mesh are a single frame of n_views plane slices: one
+// setup launch over (view, triangle), one slot sequence, one depth pass, one winner pass, one shade launch.
+int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask) {
+    if (!c || !mesh || !params) return TR_ERR_INVALID;
+    if (c->max_views < 2) return fail(c, TR_ERR_INVALID, "tr_render_views needs a context made by tr_create_views");
+    if (n_views < 1 || n_views > c->max_views) return fail(c, TR_ERR_SIZE, "tr_render_views: n_views outside [1, max_views]");
+    if (c->mode != 0) return fail(c, TR_ERR_UNSUPPORTED, "tr_render_views uses the global raster");
+    const uint64_t total = (uint64_t)n_views * (uint64_t)mesh->n_tris;
+    if (total > (uint64_t)kTriSeqMax) return fail(c, TR_ERR_SIZE, "more than 2^28-1 triangles in one batch of views");
+    for (int v = 0; v < n_views; ++v)
+        if (mesh->any_uv && (!params[v].diffuse || (params[v].use_normal_map && !params[v].normal_map)))
+            return fail(c, TR_ERR_INVALID, "mesh has texture coordinates but a texture is missing");
+    int rc = tr_clear(c);
+    if (rc != TR_OK) return rc;
+    c->n_views = n_views;
+    if (c->sel_view >= n_views) c->sel_view = 0;
+    for (int v = 0; v < n_views; ++v)
+        for (const tr_texture* t : {params[v].diffuse, params[v].normal_map})
+            if (t && std::find(c->frame_textures.begin(), c->frame_textures.end(), t) == c->frame_textures.end()) {
+                try { c->frame_textures.push_back(t); }
+                catch (...) { return fail(c, TR_ERR_OOM, "texture list"); }
+            }
+    c->draw_count = (uint32_t)n_views;
+    if (mesh->n_tris == 0) return tr_resolve(c, out_mask);
+    rc = ensure_tri_capacity(c, (size_t)total);
+    if (rc != TR_OK) return rc;
+    rc = grow_records_for(c, total);
+    if (rc != TR_OK) return rc;
+    // the views' constants: written into one of two page-locked buffers (the copy from the other may still be
+    // in flight when batches are issued back to back), uploaded on the stream
+    const int turn = c->view_turn;
+    c->view_turn ^= 1;
+    TR_HIP(c, hipEventSynchronize(c->view_ev[turn]));
+    ViewDev* stage = c->view_stage[turn];
+    for (int v = 0; v < n_views; ++v) {
+        std::memcpy(stage[v].pmv.m, params[v].pmv, sizeof(stage[v].pmv.m));
+        std::memcpy(stage[v].nmat.m, params[v].normal_mat, sizeof(stage[v].nmat.m));
+        fill_draw_dev(stage[v].draw, &params[v]);
+        stage[v].pad[0] = stage[v].pad[1] = 0;
+    }
+    TR_HIP(c, hipMemcpyAsync(c->view_table, stage, (size_t)n_views * sizeof(ViewDev), hipMemcpyHostToDevice, c->stream));
+    TR_HIP(c, hipEventRecord(c->view_ev[turn], c->stream));
+    c->draw0 = stage[0].draw;
+    const uint32_t n_halves = 2u * (uint32_t)total;
+    {
+        ProfScope ps(c, ST_SETUP);
+        SetupArgs sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.idx = mesh->idx; sa.pos = mesh->pos; sa.uvw = mesh->uvw; sa.nrm = mesh->nrm;
+        sa.n_pos = (int)mesh->n_pos; sa.n_nrm = (int)mesh->n_nrm; sa.n_tris = (int)mesh->n_tris;
+        sa.tri_base = 0; sa.draw = 0; sa.W = c->W; sa.H = c->H;
+        sa.vpm = viewport_matrix(c->W, c->H);
+        sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
+        sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+        sa.small_flag = c->small_flag;
+        sa.y_lo = 0; sa.y_hi = c->H; sa.mode = 1;
+        if (c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
+            sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots
+            sa.small_res = c->small_res;
+            c->small_any = true;
+        }
+        sa.draw_table = c->draw_table;
+        sa.half_off = c->half_off;
+        sa.views = c->view_table; sa.n_views = (uint32_t)n_views;
+        hipLaunchKernelGGL((k_setup<false, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, sa);
+        TR_HIP(c, hipGetLastError());
+        rc = launch_scan(c, 0u, n_halves);
+        if (rc != TR_OK) return rc;
+    }
+    c->view_tris = (uint32_t)mesh->n_tris;
+    c->tri_total = (uint32_t)total;
+    {
+        ProfScope ps(c, ST_DEPTH);
+        const bool big = total >= (uint64_t)c->big_draw_tris;  // many slots: build the records with one thread per slot first
+        if (big) {
+            RasterArgs ra;
+            fill_raster_args(c, ra, 0u, n_halves);
+            hipLaunchKernelGGL(k_scanlines, dim3(kScanlineBlocks), dim3(256), 0, c->stream, ra);
+            TR_HIP(c, hipGetLastError());
+        }
+        rc = launch_raster(c, 0, 0u, n_halves, false, big);
+        if (rc != TR_OK) return rc;
+        c->depth_upto = c->tri_total;
+        c->planes_clean = false;
+    }
+    return tr_resolve(c, out_mask);
+}
+
+int tr_resolve(tr_context* c, uint32_t out_mask) {
+    int rc = resolve_frame(c, out_mask, true);
+    if (rc == TR_OK && c->mode != 0) rc = settle_bin_overflow(c);
+    return rc;
+}
 
 // colour == false (shadow snapshots of an unresolved frame): winner selection and the planes asked
 // for, no shading and no colour plane; RGBA8 is then not part of resolved_mask, so that a later read
 // of the image resolves again.
 static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
     if (!c) return TR_ERR_INVALID;
+    if (c->frame_lost_texture && c->tri_total)
+        return fail(c, TR_ERR_INVALID, "a texture used by this frame's draws was destroyed: the frame cannot be resolved again (tr_clear starts a new one)");
     TR_HIP(c, hipSetDevice(c->device));
-    size_t npix = (size_t)c->W * c->H;
+    size_t npix = c->npix_all;
     out_mask &= (TR_OUT_RGBA8 | TR_OUT_Z | TR_OUT_TRI_ID | TR_OUT_RGBA_F64 | TR_OUT_KEY);
     if (colour || (out_mask & TR_OUT_RGBA_F64)) out_mask |= TR_OUT_RGBA8;
     else out_mask &= ~(uint32_t)TR_OUT_RGBA8;
@@ -1091,7 +1306,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(kTileScanThreads), 0, c->stream, c->tile_cnt, c->tile_off,
                                c->tile_list, n_tiles, c->n_tiles_padded, c->pair_cap, c->flags);
             if (c->tri_total)
-                hipLaunchKernelGGL(k_bin_fill, dim3((c->tri_total * kFillLanes + 255) / 256), dim3(256), 0, c->stream, c->rast,
+                hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((uint64_t)c->tri_total * kFillLanes + 255) / 256)), dim3(256), 0, c->stream, c->rast,
                                    c->tri_total, c->tile_off, c->tile_cnt, c->pairs, c->pair_cap, c->tiles_x, c->y_lo,
                                    c->y_hi);
             TR_HIP(c, hipGetLastError());
@@ -1142,10 +1357,15 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             TR_HIP(c, hipMemsetAsync(c->cov_counters, 0, kCounterSlots * 8 * sizeof(unsigned long long), c->stream));
         c->cov_dirty = true;
         sa.ext = c->ext_table;
-        const dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, (c->H + kShadeBH - 1) / kShadeBH);
+        const bool views = c->max_views > 1;
+        sa.view_blk_rows = c->blk_rows_per_view;
+        sa.view_pix = (uint32_t)((size_t)c->W * c->H);
+        const dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, c->blk_rows_per_view * (unsigned)(views ? c->n_views : 1));
         sa.trace = nullptr;
         static const char* shade_trace = std::getenv("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
-        if (shade_trace && !c->frame_has_ext) {
+        if (views) {
+            hipLaunchKernelGGL((k_shade<false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        } else if (shade_trace && !c->frame_has_ext) {
             const size_t words = (size_t)sgrid.x * sgrid.y * 4 * 4;
             static unsigned long long* buf = nullptr;
             static size_t buf_words = 0;
@@ -1171,7 +1391,8 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
                 if (it == sm->consumed.end()) {
                     hipEvent_t ev = nullptr;
                     TR_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                    sm->consumed.emplace_back(c, ev);
+                    try { sm->consumed.emplace_back(c, ev); }
+                    catch (...) { (void)hipEventDestroy(ev); return fail(c, TR_ERR_OOM, "shadow map consumer list"); }
                     it = sm->consumed.end() - 1;
                 }
                 TR_HIP(c, hipEventRecord(it->second, c->stream));
@@ -1217,10 +1438,10 @@ int tr_read_rgba8(tr_context* c, uint8_t* out, int flip) {
     int rc = need_plane(c, TR_OUT_RGBA8);
     if (rc != TR_OK) return rc;
     const size_t bytes = (size_t)c->W * c->H * 4;
-    const uint32_t* src = c->rgba8;
+    const uint32_t* src = c->rgba8 + (size_t)c->sel_view * c->W * c->H;
     if (flip) {  // src/helpers/mod.rs:214-218: image row = H-1-y, done on the device so that one copy delivers the image
         if (!c->flip_buf) TR_HIP(c, hipMalloc(&c->flip_buf, bytes));
-        hipLaunchKernelGGL(k_flip_rows, dim3(2048), dim3(256), 0, c->stream, c->rgba8, c->flip_buf, c->W, c->H);
+        hipLaunchKernelGGL(k_flip_rows, dim3(2048), dim3(256), 0, c->stream, src, c->flip_buf, c->W, c->H);
         TR_HIP(c, hipGetLastError());
         src = c->flip_buf;
     }
@@ -1247,13 +1468,13 @@ int tr_read_rgba8_static(tr_context* c, uint8_t* out, int flip) {
         if (fl & (1u << 6))
             return fail(c, TR_ERR_UNSUPPORTED, "tr_read_rgba8_static: bin list overflow pending; tr_get_status_flags settles it (and may allocate)");
     }
-    const uint32_t* src = c->rgba8;
+    const uint32_t* src = c->rgba8 + (size_t)c->sel_view * npix;
     if (flip) {
         uint32_t* stage = static_stage(c->device);
         if (!stage) return fail(c, TR_ERR_UNSUPPORTED, "tr_read_rgba8_static: no staging array on this device");
         // every one of the W*H words copied below is written here first: the array's old contents
         // (the last call's image, of any size) never reach the caller
-        hipLaunchKernelGGL(k_flip_rows, dim3(2048), dim3(256), 0, c->stream, c->rgba8, stage, c->W, c->H);
+        hipLaunchKernelGGL(k_flip_rows, dim3(2048), dim3(256), 0, c->stream, src, stage, c->W, c->H);
         TR_HIP(c, hipGetLastError());
         src = stage;
     }
@@ -1286,9 +1507,13 @@ int tr_get_counters(tr_context* c, uint64_t out[8]) {
         int rc = settle_bin_overflow(c);
         if (rc != TR_OK) return rc;
     }
-    std::vector<unsigned long long> tmp(kCounterSlots * 8), cov(kCounterSlots * 8);
-    TR_HIP(c, hipMemcpyAsync(tmp.data(), c->counters, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    TR_HIP(c, hipMemcpyAsync(cov.data(), c->cov_counters, cov.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    constexpr size_t kWords = (size_t)kCounterSlots * 8;
+    std::unique_ptr<unsigned long long[]> both(new (std::nothrow) unsigned long long[2 * kWords]);
+    if (!both) return fail(c, TR_ERR_OOM, "host buffer for the counters");
+    unsigned long long* tmp = both.get();
+    unsigned long long* cov = tmp + kWords;
+    TR_HIP(c, hipMemcpyAsync(tmp, c->counters, kWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    TR_HIP(c, hipMemcpyAsync(cov, c->cov_counters, kWords * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     TR_HIP(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 8; ++i) out[i] = 0;
     for (uint32_t s = 0; s < kCounterSlots; ++s) {
@@ -1337,7 +1562,7 @@ int tr_get_stream(tr_context* c, void** out_hip_stream) {
 
 int tr_device_ptr_rgba8(tr_context* c, void** out_dev_ptr) {
     if (!c || !out_dev_ptr) return TR_ERR_INVALID;
-    *out_dev_ptr = (void*)c->rgba8;
+    *out_dev_ptr = (void*)(c->rgba8 + (size_t)c->sel_view * c->W * c->H);
     return TR_OK;
 }
 
@@ -1346,6 +1571,7 @@ int tr_set_band(tr_context* c, int y_lo, int y_hi) {
     if (y_lo < 0 || y_hi > c->H || y_lo >= y_hi || (y_lo % kTile) != 0 || (y_hi != c->H && (y_hi % kTile) != 0))
         return fail(c, TR_ERR_INVALID, "band must be whole 16-pixel tile rows inside the frame");
     if (c->tri_total) return fail(c, TR_ERR_INVALID, "tr_set_band must follow tr_clear, before any draw");
+    if (c->max_views > 1 && (y_lo != 0 || y_hi != c->H)) return fail(c, TR_ERR_UNSUPPORTED, "no bands on a tr_create_views context");
     c->y_lo = y_lo;
     c->y_hi = y_hi;
     return TR_OK;
@@ -1353,6 +1579,7 @@ int tr_set_band(tr_context* c, int y_lo, int y_hi) {
 
 int tr_set_raster_mode(tr_context* c, int mode) {
     if (!c || mode < 0 || mode > 2) return TR_ERR_INVALID;
+    if (c->max_views > 1 && mode != 0) return fail(c, TR_ERR_UNSUPPORTED, "a tr_create_views context uses the global raster");
     if (c->tri_total) return fail(c, TR_ERR_INVALID, "tr_set_raster_mode must follow tr_clear, before any draw");
     if (mode != c->mode) {
         c->mode = mode;

@@ -68,6 +68,16 @@ struct DrawDev {
     int32_t pad;
 };
 
+// Batched views (tr_render_views): what differs from view to view of one mesh -- the two matrices of the vertex
+// stage (main.rs:126-135,152-153) and the fragment constants (the light is the camera position, main.rs:249).
+struct __attribute__((aligned(128))) ViewDev {
+    Mat4 pmv;      // perspective * model_view
+    Mat4 nmat;     // (model_view^T)^-1
+    DrawDev draw;
+    uint32_t pad[2];
+};
+static_assert(sizeof(ViewDev) == 384, "ViewDev must be 384 B");
+
 // EXTENSION shaders (no counterpart in the reference, whose only shader is main.rs:146-267): per
 // draw, read by k_shade<true> only.  model 0 with no shadow map is the reference's formula.
 struct DrawExt {

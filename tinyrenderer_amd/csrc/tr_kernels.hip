@@ -19,20 +19,22 @@ __global__ __launch_bounds__(256) void k_transform(const double* __restrict__ po
                                                    const double* __restrict__ nrm, int n_nrm,
                                                    Mat4 pmv, Mat4 nmat, double* __restrict__ ndc,
                                                    double* __restrict__ nout) {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id < n_pos) {
+    // (n_pos, n_nrm <= 2^28: the thread id fits 32 bits, the element offsets are formed in 64)
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t np = (size_t)n_pos, nn = (size_t)n_nrm;
+    if (id < np) {
         double g[4];
         mat4_mul_vec4(pmv, pos[3 * id], pos[3 * id + 1], pos[3 * id + 2], 1.0, g);
         ndc[id] = g[0] / g[3];
-        ndc[n_pos + id] = g[1] / g[3];
-        ndc[2 * n_pos + id] = g[2] / g[3];
-    } else if (id < n_pos + n_nrm) {
-        int k = id - n_pos;
+        ndc[np + id] = g[1] / g[3];
+        ndc[2 * np + id] = g[2] / g[3];
+    } else if (id < np + nn) {
+        const size_t k = id - np;
         double g[4];
         mat4_mul_vec4(nmat, nrm[3 * k], nrm[3 * k + 1], nrm[3 * k + 2], 0.0, g);
         nout[k] = g[0];
-        nout[n_nrm + k] = g[1];
-        nout[2 * n_nrm + k] = g[2];
+        nout[nn + k] = g[1];
+        nout[2 * nn + k] = g[2];
     }
 }
 
@@ -69,21 +71,41 @@ struct SetupArgs {
     uint32_t scan_tag;     // differs from launch to launch (never 0)
     uint32_t* half_off;    // prefix to write: half_off[scan_lo + 1 .. scan_lo + n_halves]
     uint32_t scan_lo, n_halves;
+    // batched views (k_setup<false, true>): thread g = view * n_tris + k sets up triangle k of the mesh under
+    // views[view]; its tri_seq is tri_base + g and its draw index draw + view
+    const ViewDev* views;
+    uint32_t n_views;
 };
 
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
                                               uint32_t* flags);
 
-__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1);
+__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1,
+                                               const Mat4& pmv, const Mat4& nmat, uint32_t draw, uint32_t seq);
 
 // FUSED = false: vertex stage read from k_transform's arrays, prefix by the k_scan_* kernels.
 // FUSED = true (draws of up to 256 workgroups of 64 to 256 threads): one launch does transform + setup + scan.
-template <bool FUSED>
+// VIEWS (with FUSED = false): one launch sets up every (view, triangle) of a batch of views of one mesh; the vertex
+// stage is evaluated per corner under the view's matrices (as in the fused launch), prefix by the k_scan_* kernels.
+template <bool FUSED, bool VIEWS = false>
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
+    if (VIEWS) {
+        const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+        if (g >= a.n_views * (uint32_t)a.n_tris) return;
+        const uint32_t view = g / (uint32_t)a.n_tris;
+        const int kv = (int)(g - view * (uint32_t)a.n_tris);
+        const ViewDev& vd = a.views[view];
+        if (kv == 0) a.draw_table[a.draw + view] = vd.draw;
+        uint32_t c0 = 0, c1 = 0;
+        setup_triangle(a, kv, true, c0, c1, vd.pmv, vd.nmat, a.draw + view, a.tri_base + g);
+        a.half_cnt[2 * (size_t)(a.tri_base + g)] = c0;  // (setup_triangle leaves the counts to its caller when `fused`)
+        a.half_cnt[2 * (size_t)(a.tri_base + g) + 1] = c1;
+        return;
+    }
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) a.draw_table[a.draw] = a.params;
     uint32_t c0 = 0, c1 = 0;  // slots of my triangle's two halves
-    if (k < a.n_tris) setup_triangle(a, k, FUSED, c0, c1);
+    if (k < a.n_tris) setup_triangle(a, k, FUSED, c0, c1, a.pmv, a.nmat, a.draw, a.tri_base + (uint32_t)k);
     if (!FUSED) return;
     // ---- prefix of the draw's slot counts without a second pass over them: every workgroup scans its
     // 512 counts in registers, publishes its total as ONE 8-byte word {launch tag, total} (write-through,
@@ -151,12 +173,12 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && base + tot > 0xFFFFFFFFull) atomicOr(a.flags, 1u << 4);
 }
 
-__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1) {
+__device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1,
+                                               const Mat4& pmv, const Mat4& nmat, uint32_t draw, uint32_t seq) {
     const uint32_t* ix = a.idx + 9 * (size_t)k;
     uint32_t iv[3] = {ix[0], ix[3], ix[6]};
     uint32_t it[3] = {ix[1], ix[4], ix[7]};
     uint32_t in[3] = {ix[2], ix[5], ix[8]};
-    const uint32_t seq = a.tri_base + (uint32_t)k;
     uint32_t res0 = 0, res1 = 0;
 
     double px[3], py[3], pz[3];  // clip_space_position (after divide), main.rs:154-162
@@ -164,14 +186,14 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
     for (int c = 0; c < 3; ++c) {
         if (fused) {  // k_transform's arithmetic, per corner
             double g[4];
-            mat4_mul_vec4(a.pmv, a.pos[3 * (size_t)iv[c]], a.pos[3 * (size_t)iv[c] + 1], a.pos[3 * (size_t)iv[c] + 2], 1.0, g);
+            mat4_mul_vec4(pmv, a.pos[3 * (size_t)iv[c]], a.pos[3 * (size_t)iv[c] + 1], a.pos[3 * (size_t)iv[c] + 2], 1.0, g);
             px[c] = g[0] / g[3];
             py[c] = g[1] / g[3];
             pz[c] = g[2] / g[3];
         } else {
             px[c] = a.ndc[iv[c]];
-            py[c] = a.ndc[a.n_pos + iv[c]];
-            pz[c] = a.ndc[2 * a.n_pos + iv[c]];
+            py[c] = a.ndc[(size_t)a.n_pos + iv[c]];
+            pz[c] = a.ndc[2 * (size_t)a.n_pos + iv[c]];
         }
     }
     // mod.rs:293-312: cull iff all three corners are outside on their own.
@@ -288,19 +310,19 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
             double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
             normalize3(cx, cy, cz);
             double g[4];
-            mat4_mul_vec4(a.nmat, cx, cy, cz, 0.0, g);
+            mat4_mul_vec4(nmat, cx, cy, cz, 0.0, g);
             fn[0] = g[0]; fn[1] = g[1]; fn[2] = g[2];
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (in[c] != 0xFFFFFFFFu && fused) {
                 double g[4];
-                mat4_mul_vec4(a.nmat, a.nrm[3 * (size_t)in[c]], a.nrm[3 * (size_t)in[c] + 1], a.nrm[3 * (size_t)in[c] + 2], 0.0, g);
+                mat4_mul_vec4(nmat, a.nrm[3 * (size_t)in[c]], a.nrm[3 * (size_t)in[c] + 1], a.nrm[3 * (size_t)in[c] + 2], 0.0, g);
                 S.n[c][0] = g[0]; S.n[c][1] = g[1]; S.n[c][2] = g[2];
             } else if (in[c] != 0xFFFFFFFFu) {
                 S.n[c][0] = a.nout[in[c]];
-                S.n[c][1] = a.nout[a.n_nrm + in[c]];
-                S.n[c][2] = a.nout[2 * a.n_nrm + in[c]];
+                S.n[c][1] = a.nout[(size_t)a.n_nrm + in[c]];
+                S.n[c][2] = a.nout[2 * (size_t)a.n_nrm + in[c]];
             } else {
                 S.n[c][0] = fn[0]; S.n[c][1] = fn[1]; S.n[c][2] = fn[2];
             }
@@ -337,7 +359,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
                 fl |= 2u;
             }
         }
-        S.draw = a.draw;
+        S.draw = draw;
         S.flags = fl;
         R.res[0] = res0;
         R.res[1] = res1;
@@ -645,6 +667,9 @@ struct RasterArgs {
     unsigned long long* clean_state;
     uint32_t clean_words;
     NanTable* clean_nan;
+    // batched views (tr_render_views): triangle t belongs to view t / view_tris, whose planes start view_pix
+    // pixels and whose shade blocks start view_blk blocks after the previous view's; 0 = one view
+    uint32_t view_tris, view_pix, view_blk;
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
     unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
                                 // ticks, samples | block << 32)
@@ -772,7 +797,9 @@ constexpr int kChunkSlots = 64;
 // 16-byte load per thread; wave 0 scans the sample counts; then lanes own SAMPLES: consecutive
 // lanes take consecutive samples of a scanline, i.e. consecutive pixels of a row, so the
 // depth / winner atomics of one wave-instruction fall into contiguous 8-byte slots.
-template <int PASS, bool PRECHECK, bool DBG, int kRasterThreads>
+// VIEWS: the frame is a batch of views of one mesh (tr_render_views); a slot's samples land in the plane slice
+// and the shade blocks of its triangle's view.
+template <int PASS, bool PRECHECK, bool DBG, int kRasterThreads, bool VIEWS = false>
 __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     // (timing experiments and the per-chunk timeline live in the DBG instantiations only)
     const int dbg_mode = DBG ? a.debug : 0;
@@ -781,6 +808,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     __shared__ __align__(16) uint32_t sPre[kChunkSlots + 4];  // exclusive prefix of the slots' sample counts, [64] = total
     __shared__ uint32_t sOff[PASS == 0 ? kHalfCache + 1 : 1];
     __shared__ uint32_t sEnds[2];
+    __shared__ uint32_t sView[VIEWS ? kChunkSlots : 1];  // view of each slot's triangle
     const double* sRecD = reinterpret_cast<const double*>(sRec4);
     const unsigned long long* sRecU = reinterpret_cast<const unsigned long long*>(sRec4);
 
@@ -912,6 +940,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         if (wave0) {
             sPre[lane + 1] = inc;
             if (lane == 0) sPre[0] = 0;
+            if (VIEWS) sView[lane] = (uint32_t)(sRecU[lane * 8 + 7] >> kKeyTriShift) / a.view_tris;  // (an empty slot: view 0, never read)
         }
         __syncthreads();
         const uint32_t total = sPre[64];
@@ -969,6 +998,11 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                         pix[u] = (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
                         meta[u] = (sidx << 18) | j;
                         if (PASS == 1) blk[u] = (uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW);
+                        if (VIEWS) {
+                            const uint32_t vw = sView[sidx];
+                            pix[u] += vw * a.view_pix;
+                            if (PASS == 1) blk[u] += vw * a.view_blk;
+                        }
                         if (dist != dist) {
                             st[u] = 2;
                         } else {
@@ -1088,6 +1122,9 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
         const double delta = 1.0 / (double)res;
         const bool counted = h >= a.count_h;
         bool live = false;
+        // (batched views: the triangle's view selects the plane slice and the shade blocks)
+        const uint32_t vw = a.view_tris ? tri / a.view_tris : 0u;
+        const uint32_t pix_base = vw * a.view_pix, blk_base = vw * a.view_blk;
         // depth pass: the minima of the last two pixels the half touched are still in registers (a
         // half of under a pixel alternates between two pixels from one scanline to the next);
         // winner pass: the last two pixels this thread wrote a key to
@@ -1118,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                 }
                 if (!inb) continue;
                 const double dist = -z;
-                const uint32_t pix = (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+                const uint32_t pix = pix_base + (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
                 const unsigned long long key = ((unsigned long long)tri << kKeyTriShift) | ((unsigned long long)half << kKeyHalfShift) |
                                                ((unsigned long long)i << kKeyIShift) | (unsigned long long)j;
                 if (dist != dist) {  // NaN depth: the side table, as in k_raster
@@ -1156,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                     // (samples come in key order: after a hit on a pixel, later ones on it cannot win)
                     if (pix != p0 && pix != p1 && a.depth[pix] == enc) {
                         atomicMin(&a.wkey[pix], key);
-                        a.blk_touched[2u * ((uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW))] = 1;
+                        a.blk_touched[2u * (blk_base + (uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW))] = 1;
                         p0 = p1;
                         p1 = pix;
                     }
@@ -1186,8 +1223,13 @@ template __global__ void k_small<0, true>(RasterArgs, uint8_t*);
 template __global__ void k_small<0, false>(RasterArgs, uint8_t*);
 template __global__ void k_small<1, false>(RasterArgs, uint8_t*);
 
-template __global__ void k_setup<false>(SetupArgs);
-template __global__ void k_setup<true>(SetupArgs);
+template __global__ void k_setup<false, false>(SetupArgs);
+template __global__ void k_setup<true, false>(SetupArgs);
+template __global__ void k_setup<false, true>(SetupArgs);
+template __global__ void k_raster<0, true, false, 128, true>(RasterArgs);
+template __global__ void k_raster<1, false, false, 128, true>(RasterArgs);
+template __global__ void k_raster<0, true, false, 256, true>(RasterArgs);
+template __global__ void k_raster<1, false, false, 256, true>(RasterArgs);
 template __global__ void k_raster<0, true, false, 128>(RasterArgs);
 template __global__ void k_raster<1, true, false, 128>(RasterArgs);
 template __global__ void k_raster<0, false, false, 128>(RasterArgs);
@@ -1232,6 +1274,9 @@ struct ShadeArgs {
     DrawDev draw0;         // copy of draws[0]
     const DrawExt* ext;    // k_shade<true>: per draw
     unsigned long long* trace;  // k_shade<.., true> (TR_SHADE_TRACE, tools/shade_trace.py): 4 words per wave
+    // batched views (k_shade<false, false, true>): the grid is the views stacked in y; view v owns block rows
+    // [v * view_blk_rows, (v + 1) * view_blk_rows), plane pixels from v * view_pix and draw-table entry v
+    uint32_t view_blk_rows, view_pix;
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -1280,6 +1325,16 @@ __device__ __forceinline__ uint32_t uniform_u16(const uint8_t* p) {  // p 2-byte
     return (w >> ((uint32_t)(addr & 2u) * 8u)) & 0xFFFFu;
 }
 
+__device__ __forceinline__ DrawDev uniform_drawdev(const DrawDev* p) {  // (p is the same in every lane of the wave)
+    static_assert(sizeof(DrawDev) % 8 == 0, "copied as 64-bit words");
+    union { DrawDev d; unsigned long long w[sizeof(DrawDev) / 8]; } u;
+    const __attribute__((address_space(4))) unsigned long long* q =
+        reinterpret_cast<const __attribute__((address_space(4))) unsigned long long*>((uintptr_t)p);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(DrawDev) / 8; ++i) u.w[i] = q[i];
+    return u.d;
+}
+
 // Rust `v as u8`
 __device__ __forceinline__ uint32_t f64_as_u8(double v) {
     if (!(v > 0.0)) return 0u;  // NaN, negative, zero
@@ -1309,7 +1364,9 @@ __device__ __forceinline__ double pow_exponent(double x, double e) {
 // EXT = false: the reference's shader, the tuned path of every parity test and of the benchmark.
 // EXT = true: a frame in which some draw asked for an extension shader (DrawExt); draws without one
 // still get the reference's formula, operation for operation.
-template <bool EXT, bool TRACE = false>
+// VIEWS: a batch of views of one mesh, stacked in y (tr_render_views); a wave's pixels belong to one view, whose
+// fragment constants come through the scalar cache.
+template <bool EXT, bool TRACE = false, bool VIEWS = false>
 __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     unsigned long long tr_t0 = 0;
     if (TRACE) tr_t0 = wall_clock64();
@@ -1322,9 +1379,10 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         }
     };
     const int x = blockIdx.x * kShadeBW + (threadIdx.x & (kShadeBW - 1));
-    const int y = blockIdx.y * kShadeBH + (threadIdx.x / kShadeBW);
+    const uint32_t view = VIEWS ? blockIdx.y / a.view_blk_rows : 0u;
+    const int y = (int)(blockIdx.y - view * (VIEWS ? a.view_blk_rows : 0u)) * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
-    const uint32_t pix = (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+    const uint32_t pix = (VIEWS ? view * a.view_pix : 0u) + (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
     const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
     if (a.skip_clean) {
         // Nothing landed in this block: its keys are all "none".  If the previous frame left it
@@ -1484,6 +1542,8 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         };
         // (a resolve for depth only, the snapshot of a shadow map: no shading, no colour plane)
         if (!(a.out_mask & 1u)) {
+        } else if (VIEWS) {
+            finish(uniform_drawdev(a.draws + view));  // (the batch's draws are its views, in order)
         } else if (__all(s.draw == 0u)) finish(a.draw0);  // kernel argument: scalar registers
         else finish(a.draws[s.draw]);
     }
@@ -1503,6 +1563,7 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
 template __global__ void k_shade<false, false>(ShadeArgs);
 template __global__ void k_shade<true, false>(ShadeArgs);
 template __global__ void k_shade<false, true>(ShadeArgs);
+template __global__ void k_shade<false, false, true>(ShadeArgs);
 
 __global__ void k_put_ext(DrawExt e, DrawExt* table, uint32_t draw) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[draw] = e;

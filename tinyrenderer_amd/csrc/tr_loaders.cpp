@@ -12,6 +12,8 @@
 #include <zlib.h>
 
 #include <cerrno>
+#include <charconv>
+#include <new>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,15 +64,39 @@ struct Cursor {
 bool parse_double(Cursor& c, double& out) {
     c.skip_ws();
     if (c.at_eol()) return false;
-    // strtod needs a terminated buffer: numbers are short, copy the token
-    char buf[64];
-    size_t n = 0;
-    while (c.p < c.end && n + 1 < sizeof(buf) && *c.p != ' ' && *c.p != '\t' && *c.p != '\r' && *c.p != '\n' && *c.p != '#')
-        buf[n++] = *c.p++;
-    buf[n] = 0;
-    char* e = nullptr;
-    out = std::strtod(buf, &e);  // correctly rounded, like Rust's f64 parse
-    return e != buf && *e == 0;
+    // the whole token, whatever its length, parsed in place: correctly rounded like Rust's f64 parse and
+    // independent of the process locale (strtod follows LC_NUMERIC: a comma-decimal locale would misread
+    // every vertex)
+    const char* b = c.p;
+    while (c.p < c.end && *c.p != ' ' && *c.p != '\t' && *c.p != '\r' && *c.p != '\n' && *c.p != '#') ++c.p;
+    const char* e = c.p;
+    if (b < e && *b == '+') ++b;  // (from_chars takes no leading plus sign)
+    if (b == e || *b == '+') return false;
+    const std::from_chars_result r = std::from_chars(b, e, out, std::chars_format::general);
+    if (r.ec == std::errc::invalid_argument || r.ptr != e) return false;
+    if (r.ec == std::errc::result_out_of_range) {
+        // from_chars leaves `out` alone; Rust's parse gives +-inf for too large and +-0 for too small a magnitude:
+        // the sign of the decimal exponent tells the two apart
+        const bool neg = *b == '-';
+        // decimal magnitude = position of the first non-zero digit relative to the point + the exponent field
+        long long mag = 0, expo = 0;
+        bool seen_point = false, seen_nonzero = false;
+        const char* q = b + ((*b == '-') ? 1 : 0);
+        for (; q < e && *q != 'e' && *q != 'E'; ++q) {
+            if (*q == '.') { seen_point = true; continue; }
+            if (*q != '0') seen_nonzero = true;
+            if (!seen_point && seen_nonzero) ++mag;       // integer digits from the first non-zero one
+            if (seen_point && !seen_nonzero) --mag;        // zeros between the point and the first non-zero digit
+        }
+        if (q < e) {
+            const std::from_chars_result re = std::from_chars(q + 1 + ((q + 1 < e && q[1] == '+') ? 1 : 0), e, expo);
+            if (re.ec == std::errc::result_out_of_range) expo = (q + 1 < e && q[1] == '-') ? -(1ll << 40) : (1ll << 40);
+        }
+        const bool tiny = mag + expo < 0;
+        out = tiny ? 0.0 : __builtin_huge_val();
+        if (neg) out = -out;
+    }
+    return true;
 }
 
 bool parse_index_triple(Cursor& c, long long& v, long long& t, long long& n, bool& has_t, bool& has_n) {
@@ -139,26 +165,28 @@ int parse_obj_text(const char* text, size_t len, tr_obj* o) {
         } else if (is("usemtl")) {
             if (!o->idx.empty()) geometry_closed = true;  // later faces belong to geometry[1..]
         } else if (is("f") && !geometry_closed) {
-            uint32_t corners[64][3];
+            std::vector<uint32_t> corners;  // 3 per corner; a polygon may have any number of corners
             int nc = 0;
             long long v, t = 0, n = 0;
             bool ht, hn;
-            while (nc < 64 && parse_index_triple(l, v, t, n, ht, hn)) {
+            while (parse_index_triple(l, v, t, n, ht, hn)) {
                 long long nv = (long long)(o->pos.size() / 3), nt = (long long)(o->uvw.size() / 3), nn = (long long)(o->nrm.size() / 3);
                 long long vi = v > 0 ? v - 1 : nv + v;
                 long long ti = ht ? (t > 0 ? t - 1 : nt + t) : -1;
                 long long ni = hn ? (n > 0 ? n - 1 : nn + n) : -1;
                 if (vi < 0 || vi >= nv || (ht && (ti < 0 || ti >= nt)) || (hn && (ni < 0 || ni >= nn)))
                     return load_fail(TR_ERR_INVALID, "OBJ line " + std::to_string(line_no) + ": index out of range");
-                corners[nc][0] = (uint32_t)vi;
-                corners[nc][1] = ht ? (uint32_t)ti : 0xFFFFFFFFu;
-                corners[nc][2] = hn ? (uint32_t)ni : 0xFFFFFFFFu;
+                corners.push_back((uint32_t)vi);
+                corners.push_back(ht ? (uint32_t)ti : 0xFFFFFFFFu);
+                corners.push_back(hn ? (uint32_t)ni : 0xFFFFFFFFu);
                 ++nc;
             }
+            l.skip_ws();
+            if (!l.at_eol()) return load_fail(TR_ERR_INVALID, "OBJ line " + std::to_string(line_no) + ": bad face corner");
             for (int k = 1; k + 1 < nc; ++k) {  // polygon -> triangle fan
                 const int tri[3] = {0, k, k + 1};
                 for (int q = 0; q < 3; ++q)
-                    for (int d = 0; d < 3; ++d) o->idx.push_back(corners[tri[q]][d]);
+                    for (int d = 0; d < 3; ++d) o->idx.push_back(corners[3 * (size_t)tri[q] + d]);
             }
         }
     }
@@ -305,23 +333,36 @@ extern "C" {
 
 const char* tr_load_error(void) { return g_load_error.c_str(); }
 
+// No exception may unwind through the C boundary: an allocation that fails inside a loader comes back as
+// TR_ERR_OOM, anything else as TR_ERR_INVALID.
+#define TR_GUARDED(...)                                                      \
+    try { __VA_ARGS__ }                                                      \
+    catch (const std::bad_alloc&) { return TR_ERR_OOM; }                     \
+    catch (...) { return TR_ERR_INVALID; }
+
 int tr_obj_parse(const char* text, int64_t len, tr_obj** out) {
     if (!text || len < 0 || !out) return TR_ERR_INVALID;
     *out = nullptr;
-    tr_obj* o = new (std::nothrow) tr_obj();
-    if (!o) return TR_ERR_OOM;
-    int rc = parse_obj_text(text, (size_t)len, o);
-    if (rc != TR_OK) { delete o; return rc; }
-    *out = o;
-    return TR_OK;
+    TR_GUARDED(
+        tr_obj* o = new (std::nothrow) tr_obj();
+        if (!o) return TR_ERR_OOM;
+        int rc;
+        try { rc = parse_obj_text(text, (size_t)len, o); }
+        catch (...) { delete o; throw; }
+        if (rc != TR_OK) { delete o; return rc; }
+        *out = o;
+        return TR_OK;
+    )
 }
 
 int tr_obj_load(const char* path, tr_obj** out) {
     if (!path || !out) return TR_ERR_INVALID;
     *out = nullptr;
-    std::vector<uint8_t> f;
-    if (!read_file(path, f)) return load_fail(TR_ERR_INVALID, std::string("cannot read ") + path + ": " + std::strerror(errno));
-    return tr_obj_parse((const char*)f.data(), (int64_t)f.size(), out);
+    TR_GUARDED(
+        std::vector<uint8_t> f;
+        if (!read_file(path, f)) return load_fail(TR_ERR_INVALID, std::string("cannot read ") + path + ": " + std::strerror(errno));
+        return tr_obj_parse((const char*)f.data(), (int64_t)f.size(), out);
+    )
 }
 
 int tr_obj_counts(const tr_obj* o, int64_t* n_positions, int64_t* n_uvw, int64_t* n_normals, int64_t* n_triangles) {
@@ -341,31 +382,40 @@ void tr_obj_free(tr_obj* o) { delete o; }
 int tr_image_load_rgba8(const char* path, int flip_vertically, tr_image** out) {
     if (!path || !out) return TR_ERR_INVALID;
     *out = nullptr;
-    std::vector<uint8_t> f;
-    if (!read_file(path, f)) return load_fail(TR_ERR_INVALID, std::string("cannot read ") + path + ": " + std::strerror(errno));
-    tr_image* img = new (std::nothrow) tr_image();
-    if (!img) return TR_ERR_OOM;
-    int rc;
-    if (f.size() >= 8 && f[0] == 0x89 && f[1] == 'P') rc = decode_png(f, img);
-    else {
-        const char* dot = std::strrchr(path, '.');
-        if (dot && (!strcasecmp(dot, ".tga") || !strcasecmp(dot, ".icb") || !strcasecmp(dot, ".vda") || !strcasecmp(dot, ".vst"))) rc = decode_tga(f, img);
-        else rc = load_fail(TR_ERR_UNSUPPORTED, "unsupported image format (PNG and TGA are decoded)");
-    }
-    if (rc != TR_OK) { delete img; return rc; }
-    if (flip_vertically) {  // src/helpers/mod.rs:291-302
-        const size_t row = (size_t)img->w * 4;
-        std::vector<uint8_t> tmp(row);
-        for (int y = 0; y < img->h / 2; ++y) {
-            uint8_t* a = &img->rgba[row * y];
-            uint8_t* b = &img->rgba[row * (size_t)(img->h - 1 - y)];
-            std::memcpy(tmp.data(), a, row);
-            std::memcpy(a, b, row);
-            std::memcpy(b, tmp.data(), row);
+    tr_image* img = nullptr;
+    try {
+        std::vector<uint8_t> f;
+        if (!read_file(path, f)) return load_fail(TR_ERR_INVALID, std::string("cannot read ") + path + ": " + std::strerror(errno));
+        img = new (std::nothrow) tr_image();
+        if (!img) return TR_ERR_OOM;
+        int rc;
+        if (f.size() >= 8 && f[0] == 0x89 && f[1] == 'P') rc = decode_png(f, img);
+        else {
+            const char* dot = std::strrchr(path, '.');
+            if (dot && (!strcasecmp(dot, ".tga") || !strcasecmp(dot, ".icb") || !strcasecmp(dot, ".vda") || !strcasecmp(dot, ".vst"))) rc = decode_tga(f, img);
+            else rc = load_fail(TR_ERR_UNSUPPORTED, "unsupported image format (PNG and TGA are decoded)");
         }
+        if (rc != TR_OK) { delete img; return rc; }
+        if (flip_vertically) {  // src/helpers/mod.rs:291-302
+            const size_t row = (size_t)img->w * 4;
+            std::vector<uint8_t> tmp(row);
+            for (int y = 0; y < img->h / 2; ++y) {
+                uint8_t* a = &img->rgba[row * y];
+                uint8_t* b = &img->rgba[row * (size_t)(img->h - 1 - y)];
+                std::memcpy(tmp.data(), a, row);
+                std::memcpy(a, b, row);
+                std::memcpy(b, tmp.data(), row);
+            }
+        }
+        *out = img;
+        return TR_OK;
+    } catch (const std::bad_alloc&) {
+        delete img;
+        return TR_ERR_OOM;
+    } catch (...) {
+        delete img;
+        return TR_ERR_INVALID;
     }
-    *out = img;
-    return TR_OK;
 }
 int tr_image_size(const tr_image* img, int* width, int* height) {
     if (!img) return TR_ERR_INVALID;
@@ -380,6 +430,7 @@ void tr_image_free(tr_image* img) { delete img; }
 // (row 0 = top), filter 0 on every row, one zlib stream in one IDAT.
 int tr_image_write_png(const char* path, const uint8_t* rgba8, int width, int height) {
     if (!path || !rgba8 || width < 1 || height < 1) return TR_ERR_INVALID;
+    TR_GUARDED(
     const size_t row = (size_t)width * 4;
     std::vector<uint8_t> raw((row + 1) * (size_t)height);
     for (int y = 0; y < height; ++y) {
@@ -414,6 +465,7 @@ int tr_image_write_png(const char* path, const uint8_t* rgba8, int width, int he
     chunk("IEND", nullptr, 0);
     ok = (std::fclose(f) == 0) && ok;
     return ok ? TR_OK : load_fail(TR_ERR_INVALID, std::string("short write to ") + path);
+    )
 }
 
 }  // extern "C"

@@ -81,9 +81,9 @@ __global__ __launch_bounds__(256) void k_bin_fill(const TriRaster* __restrict__ 
                                                   const uint32_t* __restrict__ tile_off, uint32_t* cursor,
                                                   uint32_t* pairs, uint32_t pair_cap, int tiles_x, int y_lo,
                                                   int y_hi) {
-    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t k = gid / kFillLanes;
-    int q = (int)(gid % kFillLanes);
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n_tris * 16 may pass 2^32)
+    const uint32_t k = (uint32_t)(gid / kFillLanes);
+    const int q = (int)(gid % kFillLanes);
     if (k >= n_tris) return;
     const TriRaster& r = rast[k];
     if (!r.res[0]) return;

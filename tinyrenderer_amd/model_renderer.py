@@ -192,12 +192,18 @@ class ModelRendererState:
     """src/model_renderer/mod.rs:29-35,150-173.  `frame_buffer` / `z_buffer` are read back from
     the GPU on access, in the reference's (W, H, C) layout."""
 
-    def __init__(self, frame_width, frame_height, device=0, raster_mode=None):
+    def __init__(self, frame_width, frame_height, device=0, raster_mode=None, max_views=1):
+        """`max_views` > 1: a state whose planes hold that many W x H slices, for `render_views`
+        (tr_create_views; the reference renders one view per loop iteration, main.rs:57-116)."""
         self._lib = _ffi.load()
         self.frame_width = int(frame_width)
         self.frame_height = int(frame_height)
+        self.max_views = int(max_views)
         ctx = C.c_void_p()
-        rc = self._lib.tr_create(int(device), self.frame_width, self.frame_height, C.byref(ctx))
+        if self.max_views > 1:
+            rc = self._lib.tr_create_views(int(device), self.frame_width, self.frame_height, self.max_views, C.byref(ctx))
+        else:
+            rc = self._lib.tr_create(int(device), self.frame_width, self.frame_height, C.byref(ctx))
         if rc != _ffi.TR_OK:
             raise _ffi.TrError(
                 f"tr_create failed: {_ffi.TR_ERR.get(rc, rc)} (a gfx950 GPU is required; there is no CPU fallback)")
@@ -283,6 +289,10 @@ class ModelRendererState:
         _ffi.check(self._ctx, self._lib.tr_read_rgba8(self._ctx, self._pinned, 1), "tr_read_rgba8")
         return np.ctypeslib.as_array((C.c_uint8 * n).from_address(self._pinned)).reshape(shape)
 
+    def select_view(self, view):
+        """The slice of a `render_views` batch that `z_buffer`, `frame_buffer`, `present()` ... refer to."""
+        _ffi.check(self._ctx, self._lib.tr_select_view(self._ctx, int(view)), "tr_select_view")
+
     def set_band(self, y_lo, y_hi):
         """Restrict this context to pixel rows [y_lo, y_hi) (whole 16-pixel tile rows); call after
         clear_screen and before the first draw."""
@@ -345,6 +355,20 @@ def make_draw_params(state, shader, texture, normal_map):
     p.diffuse = state._texture_handle(texture)
     p.normal_map = state._texture_handle(normal_map)
     return p
+
+
+def render_views(model_renderer_state, mesh_component, shaders, out_mask=_ffi.TR_OUT_RGBA8):
+    """One iteration of the reference's loop per shader -- `clear_screen` + `render_mesh_component(state,
+    &mesh, VS, FS)` (src/main.rs:57-116,272-273) -- for ONE mesh under len(shaders) cameras, as a single batch
+    (tr_render_views): view v lands in slice v of a state made with `max_views`; `select_view(v)` picks the slice
+    the buffers read."""
+    s = model_renderer_state
+    n = len(shaders)
+    arr = (_ffi.DrawParams * n)()
+    for v, sh in enumerate(shaders):
+        arr[v] = make_draw_params(s, sh, mesh_component.texture, mesh_component.normal_map)
+    rc = s._lib.tr_render_views(s._ctx, s._mesh_handle(mesh_component.mesh), arr, n, out_mask)
+    _ffi.check(s._ctx, rc, "tr_render_views")
 
 
 def make_shade_ext(state, ext):
