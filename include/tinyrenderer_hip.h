@@ -92,6 +92,9 @@ int tr_clear(tr_context* ctx);
 int tr_mesh_create(tr_context* ctx, const double* positions, int64_t n_positions,
                    const double* normals, int64_t n_normals, const double* uvw, int64_t n_uvw,
                    const uint32_t* idx, int64_t n_triangles, tr_mesh** out_mesh);
+/* Lifetime: a draw of 65 536 triangles or more builds its per-triangle shade records at resolve time (only for the
+ * triangles that own a pixel) and reads the mesh again then: destroying such a mesh before the next tr_clear leaves
+ * what is resolved readable and makes a further resolve of the frame fail with TR_ERR_INVALID. */
 int tr_mesh_destroy(tr_context* ctx, tr_mesh* mesh);
 
 /* Replaces MyRgbaImage after flip_vertically (src/model_renderer/mod.rs:40-41,

@@ -587,6 +587,62 @@ def test_texture_destroyed_under_a_recorded_frame(oracle):
         st.close()
 
 
+def test_deferred_shade_records(oracle, monkeypatch):
+    """Draws of 65 536 triangles or more write no TriShade in k_setup; k_build_shade writes it before the shade pass
+    for the triangles the winner pass flagged.  Forced onto every draw here (TR_DEFER_SHADE=1 with the unfused
+    front end), with and without the small-triangle path: two draws, NaN depths, a frame extended after a resolve,
+    a late plane request, and a mesh destroyed under its recorded frame."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader, ModelRendererState, clear_screen, render_mesh_component
+
+    monkeypatch.setenv("TR_DEFER_SHADE", "1")
+    monkeypatch.setenv("TR_FUSED_FRONT", "0")
+    for small in ("1", "1000000000"):
+        monkeypatch.setenv("TR_SMALL_DRAW", small)
+        for W, Hh in ((64, 48), (320, 200)):
+            draws = _head_scene(W, Hh, with_eye=True)
+            o = SU.oracle_render(oracle, W, Hh, draws)
+            g = SU.gpu_render(W, Hh, draws, mode=0)
+            info = SU.assert_parity(o, g)
+            assert info["f64_colour_mismatches"] == 0
+        N = H.NONE_INDEX
+        degenerate = H.Object([[-0.5, 0.25, 0.0], [0.5, 0.25, 0.0], [0.0, 0.25, 0.0]],
+                              [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)), [[0, 0, N, 1, 1, N, 2, 2, N]])
+        big = H.Object([[-1, -1, 0.5], [1, -1, 0.5], [-1, 1, 0.5]], np.zeros((0, 3)), np.zeros((0, 3)),
+                       [[0, N, N, 1, N, N, 2, N, N]])
+        d, b = _synthetic_component(degenerate), _synthetic_component(big)
+        sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+        for order in ((d, b), (b, d)):
+            for W, Hh in ((8, 8), (50, 37)):
+                frame = [(mc, sh) for mc in order]
+                SU.assert_parity(SU.oracle_render(oracle, W, Hh, frame), SU.gpu_render(W, Hh, frame, mode=0))
+        W, Hh = 160, 120
+        draws = _head_scene(W, Hh, with_eye=True)
+        o1, o2 = SU.oracle_render(oracle, W, Hh, draws[:1]), SU.oracle_render(oracle, W, Hh, draws)
+        st = ModelRendererState(W, Hh, raster_mode=0)
+        try:
+            clear_screen(st)
+            render_mesh_component(st, *draws[0])
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            assert np.array_equal(st.present(), o1["present"])
+            assert np.array_equal(st.frame_buffer.view(np.uint64), o1["fb"].view(np.uint64))  # late plane: shaded again
+            render_mesh_component(st, *draws[1])
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            assert np.array_equal(st.present(), o2["present"])
+            # the head's mesh goes away under the recorded frame: resolved planes stay, a new resolve is refused
+            mesh = st._meshes.pop(id(draws[0][0].mesh))
+            assert st._lib.tr_mesh_destroy(st._ctx, mesh) == 0
+            assert np.array_equal(st.present(), o2["present"])
+            with pytest.raises(_ffi.TrError, match="destroyed"):
+                st.frame_buffer
+            clear_screen(st)
+            render_mesh_component(st, *draws[0])
+            assert np.array_equal(st.present(), o1["present"])
+        finally:
+            st.close()
+
+
 def test_small_triangle_path(oracle, monkeypatch):
     """k_small (one thread per triangle half, taken by triangles of at most 9 scanlines per half in
     draws of 65 536 triangles or more): forced onto every draw here.  Whole frames, counters, bands,

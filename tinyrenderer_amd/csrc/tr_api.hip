@@ -54,6 +54,7 @@ struct tr_context {
     int device = 0;
     int W = 0, H = 0;
     int y_lo = 0, y_hi = 0;
+    int shaded_lo = 0, shaded_hi = 0;  // rows the last shade launch covered (a band context shades its band's rows only)
     // batched views (tr_create_views / tr_render_views): the planes hold max_views slices of W x H pixels
     int max_views = 1;
     int n_views = 1;                 // slices the current frame covers (1 unless the frame is a tr_render_views batch)
@@ -91,6 +92,11 @@ struct tr_context {
     uint32_t* flip_buf = nullptr;    // tr_read_rgba8(flip): the presented image, flipped on the device
     uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
+    uint8_t* need_shade = nullptr;   // deferred shade records: per triangle, flagged by the winner pass (tri_cap bytes)
+    uint32_t defer_tris = 65536;     // draws with at least this many triangles defer their shade records (TR_DEFER_SHADE)
+    struct Deferred { const tr_mesh* mesh; SetupArgs sa; };
+    std::vector<Deferred> deferred;  // such draws since tr_clear: k_build_shade runs for each before the shade pass
+    bool frame_lost_mesh = false;    // the mesh of one of them was destroyed: the frame cannot be shaded again
     bool counted = false;            // in g_live_contexts
     int raster_threads = 0;          // TR_RASTER_THREADS=128|256 pins the raster workgroup size (0: by live contexts)
     bool small_path = true;          // TR_SMALL_TRIS=0 disables k_small
@@ -227,7 +233,9 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     TriRaster* nr = nullptr;
     TriShade* ns = nullptr;
     uint32_t *ncnt = nullptr, *noff = nullptr;
-    uint8_t *nlive = nullptr, *nsmall = nullptr;
+    uint8_t *nlive = nullptr, *nsmall = nullptr, *nneed = nullptr;
+
+    TR_HIP(c, hipMalloc(&nneed, cap));
     TR_HIP(c, hipMalloc(&nlive, 2 * cap));
     TR_HIP(c, hipMalloc(&nsmall, cap));
     TR_HIP(c, hipMemsetAsync(nsmall, 0, cap, c->stream));
@@ -243,6 +251,7 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
         TR_HIP(c, hipMemcpyAsync(noff, c->half_off, (2 * n + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(nlive, c->half_live, 2 * n, hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(nsmall, c->small_flag, n, hipMemcpyDeviceToDevice, c->stream));
+        TR_HIP(c, hipMemcpyAsync(nneed, c->need_shade, n, hipMemcpyDeviceToDevice, c->stream));
     } else if (c->half_off) {
         TR_HIP(c, hipMemcpyAsync(noff, c->half_off, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
@@ -250,8 +259,9 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     }
     TR_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt); (void)hipFree(c->half_off);
-    (void)hipFree(c->half_live); (void)hipFree(c->small_flag);
+    (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade);
     c->rast = nr; c->shade = ns; c->half_cnt = ncnt; c->half_off = noff; c->half_live = nlive; c->small_flag = nsmall;
+    c->need_shade = nneed;
     c->tri_cap = cap;
     size_t tiles = (2 * cap + kScanTile - 1) / kScanTile;
     if (tiles > c->tile_cap) {
@@ -318,6 +328,7 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.clean_state = nullptr;
     ra.clean_words = 0;
     ra.clean_nan = nullptr;
+    ra.need_shade = c->deferred.empty() ? nullptr : c->need_shade;
     ra.view_tris = c->view_tris;
     ra.view_pix = (uint32_t)((size_t)c->W * c->H);
     ra.view_blk = c->blk_per_view;
@@ -388,6 +399,11 @@ int grow_records_for(tr_context* c, uint64_t n_tris) {
     return TR_OK;
 }
 
+bool shade_trace_on() {
+    static const bool on = std::getenv("TR_SHADE_TRACE") != nullptr;
+    return on;
+}
+
 constexpr int kMaxDevices = 64;
 std::atomic<int> g_live_contexts[kMaxDevices];  // per device (zero-initialised)
 
@@ -437,6 +453,13 @@ void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block
 #undef TR_LAUNCH
 }
 
+// Workgroups of a k_small launch over at most n_halves halves: one thread per half up to a grid that fills the GPU
+// a few times over, the threads stride beyond that.
+unsigned small_grid(uint32_t n_halves) {
+    const uint32_t want = (n_halves + 255u) / 256u;
+    return want < 1u ? 1u : (want > 8192u ? 8192u : want);
+}
+
 // passes 0 / 1 over the half range [h_lo, h_hi)
 int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool use_live = false, bool rec_ready = false) {
     RasterArgs ra;
@@ -479,14 +502,14 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
         launch_k_raster<0>(c->precheck, dbg, threads, grid, block, c->stream, ra);
         if (c->small_any) {
-            const dim3 sg((h_hi - h_lo + 255u) / 256u);
+            const dim3 sg(small_grid(h_hi - h_lo));
             if (c->precheck) hipLaunchKernelGGL((k_small<0, true>), sg, dim3(256), 0, c->stream, ra, c->half_live);
             else hipLaunchKernelGGL((k_small<0, false>), sg, dim3(256), 0, c->stream, ra, c->half_live);
         }
         if (h_hi / 2u > c->counted_upto) c->counted_upto = h_hi / 2u;
     } else {
         if (c->small_any)  // (before k_raster<1>, whose tail zeroes the other half of the per-frame state)
-            hipLaunchKernelGGL((k_small<1, false>), dim3((h_hi - h_lo + 255u) / 256u), dim3(256), 0, c->stream, ra, c->half_live);
+            hipLaunchKernelGGL((k_small<1, false>), dim3(small_grid(h_hi - h_lo)), dim3(256), 0, c->stream, ra, c->half_live);
         // measured on MI355X (4K african_head): the winner pass is faster without the filter
         // (44 vs 52 us), the depth pass with it (71 vs 93 us)
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
@@ -643,6 +666,8 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     c->H = height;
     c->y_lo = 0;
     c->y_hi = height;
+    c->shaded_lo = 0;
+    c->shaded_hi = height;
     c->max_views = max_views;
     c->n_views = max_views;  // (an empty frame resolves every slice)
     c->npix_all = (size_t)width * height * (size_t)max_views;
@@ -661,6 +686,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (const char* e = std::getenv("TR_SMALL_RES")) c->small_res = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SMALL_DRAW")) c->small_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TR_DEFER_SHADE")) c->defer_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SCAN_RECORDS")) {
         c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
         c->rec_auto = false;
@@ -757,7 +783,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -818,6 +844,8 @@ int tr_clear(tr_context* c) {
     c->frame_maps.clear();
     c->frame_textures.clear();
     c->frame_lost_texture = false;
+    c->deferred.clear();
+    c->frame_lost_mesh = false;
     c->small_any = false;
     c->view_tris = 0;
     c->n_views = c->max_views;  // (an empty frame resolves every slice)
@@ -876,6 +904,9 @@ int tr_mesh_destroy(tr_context* c, tr_mesh* m) {
     if (!m) return TR_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    // a draw whose shade records are built at resolve time (large draws) reads the mesh again then
+    for (const auto& d : c->deferred)
+        if (d.mesh == m) c->frame_lost_mesh = true;
     (void)hipFree(m->pos); (void)hipFree(m->nrm); (void)hipFree(m->uvw); (void)hipFree(m->idx);
     delete m;
     return TR_OK;
@@ -1028,17 +1059,22 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     if (rc != TR_OK) return rc;
     rc = grow_records_for(c, (uint64_t)mesh->n_tris);
     if (rc != TR_OK) return rc;
-    rc = ensure_scratch(c, &c->ndc, &c->ndc_cap, (size_t)mesh->n_pos * 3);
-    if (rc != TR_OK) return rc;
-    rc = ensure_scratch(c, &c->nout, &c->nout_cap, (size_t)(mesh->n_nrm ? mesh->n_nrm : 1) * 3);
-    if (rc != TR_OK) return rc;
+    // small draws (the reference's meshes): one launch does vertex stage + setup + prefix
+    const bool fused = c->fused_front && c->mode != 1 && (uint64_t)mesh->n_tris <= 16384u;  // (at most 256 workgroups, of 64 threads at the least: k_setup<true>)
+    // large draws: no shade record at setup time (k_build_shade writes it for the triangles the winner pass flags),
+    // and so no normals and each position once per corner: no k_transform launch either
+    const bool defer = c->mode == 0 && !fused && (uint64_t)mesh->n_tris >= (uint64_t)c->defer_tris;
+    if (!fused && !defer) {
+        rc = ensure_scratch(c, &c->ndc, &c->ndc_cap, (size_t)mesh->n_pos * 3);
+        if (rc != TR_OK) return rc;
+        rc = ensure_scratch(c, &c->nout, &c->nout_cap, (size_t)(mesh->n_nrm ? mesh->n_nrm : 1) * 3);
+        if (rc != TR_OK) return rc;
+    }
 
     Mat4 pmv, nmat;
     std::memcpy(pmv.m, p->pmv, sizeof(pmv.m));
     std::memcpy(nmat.m, p->normal_mat, sizeof(nmat.m));
-    // small draws (the reference's meshes): one launch does vertex stage + setup + prefix
-    const bool fused = c->fused_front && c->mode != 1 && (uint64_t)mesh->n_tris <= 16384u;  // (at most 256 workgroups, of 64 threads at the least: k_setup<true>)
-    if (!fused) {
+    if (!fused && !defer) {
         ProfScope ps(c, ST_TRANSFORM);
         const int64_t n = mesh->n_pos + mesh->n_nrm;  // (<= 2^29: tr_mesh_create)
         hipLaunchKernelGGL(k_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, mesh->pos, (int)mesh->n_pos,
@@ -1065,6 +1101,9 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
             sa.small_res = c->small_res;
             c->small_any = true;
         }
+        sa.need_shade = c->need_shade;
+        if (defer) sa.mode |= 8;  // no TriShade now: k_build_shade writes it for the triangles the winner pass flags
+        sa.per_corner = defer ? 1 : 0;
         DrawDev& d = sa.params;
         fill_draw_dev(d, p);
         sa.draw_table = c->draw_table;
@@ -1074,6 +1113,10 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.scan_tag = c->scan_tag;
         sa.scan_lo = 2u * tri_base; sa.n_halves = n_halves;
         sa.views = nullptr; sa.n_views = 0;
+        if (defer) {
+            try { c->deferred.push_back({mesh, sa}); }
+            catch (...) { return fail(c, TR_ERR_OOM, "deferred draw list"); }
+        }
         if (fused) {
             // (measured: 128 threads per workgroup; 64 / 256 cost the orbit rehearsal 1 % / 4 % with four contexts)
             static const int st = std::getenv("TR_SETUP_THREADS") ? std::atoi(std::getenv("TR_SETUP_THREADS")) : 128;
@@ -1222,8 +1265,8 @@ int tr_resolve(tr_context* c, uint32_t out_mask) {
 // of the image resolves again.
 static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
     if (!c) return TR_ERR_INVALID;
-    if (c->frame_lost_texture && c->tri_total)
-        return fail(c, TR_ERR_INVALID, "a texture used by this frame's draws was destroyed: the frame cannot be resolved again (tr_clear starts a new one)");
+    if ((c->frame_lost_texture || c->frame_lost_mesh) && c->tri_total)
+        return fail(c, TR_ERR_INVALID, "a texture or mesh used by this frame's draws was destroyed: the frame cannot be resolved again (tr_clear starts a new one)");
     TR_HIP(c, hipSetDevice(c->device));
     size_t npix = c->npix_all;
     out_mask &= (TR_OUT_RGBA8 | TR_OUT_Z | TR_OUT_TRI_ID | TR_OUT_RGBA_F64 | TR_OUT_KEY);
@@ -1337,6 +1380,16 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             TR_HIP(c, hipGetLastError());
         }
     }
+    if ((out_mask & TR_OUT_RGBA8) && c->mode == 0) {
+        // shade records of the large draws, for the triangles the winner pass flagged
+        for (auto& d : c->deferred) {
+            ProfScope ps(c, ST_SETUP);
+            SetupArgs ba = d.sa;
+            ba.rast = c->rast; ba.shade = c->shade;  // (the arrays may have grown since the draw)
+            hipLaunchKernelGGL(k_build_shade, dim3((unsigned)((ba.n_tris + 255) / 256)), dim3(256), 0, c->stream, ba, c->need_shade);
+            TR_HIP(c, hipGetLastError());
+        }
+    }
     {
         ProfScope ps(c, ST_SHADE);
         ShadeArgs sa;
@@ -1360,7 +1413,17 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         const bool views = c->max_views > 1;
         sa.view_blk_rows = c->blk_rows_per_view;
         sa.view_pix = (uint32_t)((size_t)c->W * c->H);
-        const dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, c->blk_rows_per_view * (unsigned)(views ? c->n_views : 1));
+        dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, c->blk_rows_per_view * (unsigned)(views ? c->n_views : 1));
+        sa.blk_y0 = 0;
+        if (!views && !shade_trace_on() && out_mask == TR_OUT_RGBA8 && (c->y_lo > 0 || c->y_hi < c->H || c->shaded_lo > 0 || c->shaded_hi < c->H)) {
+            // a band context (RGBA8 only: the other planes are rewritten whole): nothing lands outside [y_lo, y_hi); the
+            // rows the previous launch covered are included so that a band that moved (balanced_bands re-cuts between frames) leaves no stale colour behind
+            const int lo = c->y_lo < c->shaded_lo ? c->y_lo : c->shaded_lo, hi = c->y_hi > c->shaded_hi ? c->y_hi : c->shaded_hi;
+            sa.blk_y0 = (uint32_t)(lo / kShadeBH);
+            sgrid.y = (unsigned)((hi + kShadeBH - 1) / kShadeBH) - sa.blk_y0;
+        }
+        c->shaded_lo = c->y_lo;
+        c->shaded_hi = c->y_hi;
         sa.trace = nullptr;
         static const char* shade_trace = std::getenv("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
         if (views) {

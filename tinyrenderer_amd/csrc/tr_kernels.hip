@@ -57,9 +57,11 @@ struct SetupArgs {
     uint32_t* tile_cnt;    // triangles per tile (tile raster only)
     int tiles_x, tiles_y;
     int y_lo, y_hi;        // band of pixel rows owned by this context
-    int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small)
+    int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small),
+                           // bit3: no TriShade now (k_build_shade writes it for the triangles the winner pass flags)
     uint32_t small_res;    // a triangle is small if neither half has more than small_res + 1 scanlines
     uint8_t* small_flag;   // per triangle: 1 = flagged kTriSmall (what k_small reads)
+    uint8_t* need_shade;   // per triangle, draws with deferred shade records (mode bit 3): zeroed here, set by the winner pass
     uint32_t* flags;
     DrawDev params;
     DrawDev* draw_table;
@@ -75,6 +77,7 @@ struct SetupArgs {
     // views[view]; its tri_seq is tri_base + g and its draw index draw + view
     const ViewDev* views;
     uint32_t n_views;
+    int per_corner;        // k_setup<false, false>: evaluate the vertex stage per corner instead of reading ndc / nout
 };
 
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
@@ -105,7 +108,15 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) a.draw_table[a.draw] = a.params;
     uint32_t c0 = 0, c1 = 0;  // slots of my triangle's two halves
-    if (k < a.n_tris) setup_triangle(a, k, FUSED, c0, c1, a.pmv, a.nmat, a.draw, a.tri_base + (uint32_t)k);
+    if (k < a.n_tris) {
+        // (per_corner: a draw whose shade records are deferred needs no normals here and its positions once per
+        // corner: the vertex stage is evaluated in place, there is no k_transform launch and no ndc array)
+        setup_triangle(a, k, FUSED || a.per_corner, c0, c1, a.pmv, a.nmat, a.draw, a.tri_base + (uint32_t)k);
+        if (!FUSED && a.per_corner && (a.mode & 1)) {  // (setup_triangle leaves the counts to its caller when `fused`)
+            a.half_cnt[2 * (size_t)(a.tri_base + (uint32_t)k)] = c0;
+            a.half_cnt[2 * (size_t)(a.tri_base + (uint32_t)k) + 1] = c1;
+        }
+    }
     if (!FUSED) return;
     // ---- prefix of the draw's slot counts without a second pass over them: every workgroup scans its
     // 512 counts in registers, publishes its total as ONE 8-byte word {launch tag, total} (write-through,
@@ -173,6 +184,89 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && base + tot > 0xFFFFFFFFull) atomicOr(a.flags, 1u << 4);
 }
 
+// The per-triangle record of the shade pass (mod.rs:329,333-358 and the vertex-shader outputs of main.rs:164-171):
+// unsorted viewport x / y, the three normals, uvs, tangent and bitangent.  px/py/pz: clip_space_position after the
+// divide; vx/vy: viewport x / y.
+__device__ __forceinline__ TriShade make_shade_record(const SetupArgs& a, const uint32_t iv[3], const uint32_t it[3],
+                                                      const uint32_t in[3], const double px[3], const double py[3],
+                                                      const double pz[3], const double vx[3], const double vy[3],
+                                                      bool fused, const Mat4& nmat, uint32_t draw) {
+    TriShade S;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        S.ux[c] = vx[c];
+        S.uy[c] = vy[c];
+    }
+    // normals: indexed (mod.rs:253-258) or the face normal (mod.rs:245-252)
+    bool need_face = in[0] == 0xFFFFFFFFu || in[1] == 0xFFFFFFFFu || in[2] == 0xFFFFFFFFu;
+    double fn[3] = {0, 0, 0};
+    if (need_face) {
+        double v[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            for (int d = 0; d < 3; ++d) v[c][d] = a.pos[3 * (size_t)iv[c] + d];
+        double ax = v[1][0] - v[0][0], ay = v[1][1] - v[0][1], az = v[1][2] - v[0][2];
+        normalize3(ax, ay, az);
+        double bx = v[2][0] - v[1][0], by = v[2][1] - v[1][1], bz = v[2][2] - v[1][2];
+        normalize3(bx, by, bz);
+        double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+        normalize3(cx, cy, cz);
+        double g[4];
+        mat4_mul_vec4(nmat, cx, cy, cz, 0.0, g);
+        fn[0] = g[0]; fn[1] = g[1]; fn[2] = g[2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (in[c] != 0xFFFFFFFFu && fused) {
+            double g[4];
+            mat4_mul_vec4(nmat, a.nrm[3 * (size_t)in[c]], a.nrm[3 * (size_t)in[c] + 1], a.nrm[3 * (size_t)in[c] + 2], 0.0, g);
+            S.n[c][0] = g[0]; S.n[c][1] = g[1]; S.n[c][2] = g[2];
+        } else if (in[c] != 0xFFFFFFFFu) {
+            S.n[c][0] = a.nout[in[c]];
+            S.n[c][1] = a.nout[(size_t)a.n_nrm + in[c]];
+            S.n[c][2] = a.nout[2 * (size_t)a.n_nrm + in[c]];
+        } else {
+            S.n[c][0] = fn[0]; S.n[c][1] = fn[1]; S.n[c][2] = fn[2];
+        }
+    }
+    uint32_t fl = 0;
+    bool has_uv = it[0] != 0xFFFFFFFFu && it[1] != 0xFFFFFFFFu && it[2] != 0xFFFFFFFFu;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        S.uv[c][0] = has_uv ? a.uvw[3 * (size_t)it[c]] : 0.0;
+        S.uv[c][1] = has_uv ? a.uvw[3 * (size_t)it[c] + 1] : 0.0;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { S.t[d] = 0.0; S.b[d] = 0.0; }
+    if (has_uv) {
+        fl |= 1u;
+        // mod.rs:339-351; 2x2 try_inverse and the (2x2)*(2x3) product as nalgebra does them.
+        double m11 = S.uv[1][0] - S.uv[0][0], m12 = S.uv[1][1] - S.uv[0][1];
+        double m21 = S.uv[2][0] - S.uv[0][0], m22 = S.uv[2][1] - S.uv[0][1];
+        double e0[3] = {px[1] - px[0], py[1] - py[0], pz[1] - pz[0]};
+        double e1[3] = {px[2] - px[0], py[2] - py[0], pz[2] - pz[0]};
+        double det = m11 * m22 - m21 * m12;
+        if (det != 0.0) {
+            double i11 = m22 / det, i12 = -m12 / det, i21 = -m21 / det, i22 = m11 / det;
+            double t[3], b[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                t[d] = i12 * e1[d] + i11 * e0[d];
+                b[d] = i22 * e1[d] + i21 * e0[d];
+            }
+            normalize4_w0(t[0], t[1], t[2]);
+            normalize4_w0(b[0], b[1], b[2]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { S.t[d] = t[d]; S.b[d] = b[d]; }
+            fl |= 2u;
+        }
+    }
+    S.draw = draw;
+    S.flags = fl;
+    S.pad[0] = S.pad[1] = S.pad[2] = S.pad[3] = 0;
+    return S;
+}
+
 __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1,
                                                const Mat4& pmv, const Mat4& nmat, uint32_t draw, uint32_t seq) {
     const uint32_t* ix = a.idx + 9 * (size_t)k;
@@ -205,7 +299,6 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         cull = cull && out;
     }
     TriRaster R;
-    TriShade S;
     bool small = false;
     R.res[0] = R.res[1] = 0;
     R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0; R.slot_shift = 0;
@@ -289,78 +382,8 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
                 R.sp[d] = sp[d];
             }
         }
-        // ---- shade record
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            S.ux[c] = vx[c];
-            S.uy[c] = vy[c];
-        }
-        // normals: indexed (mod.rs:253-258) or the face normal (mod.rs:245-252)
-        bool need_face = in[0] == 0xFFFFFFFFu || in[1] == 0xFFFFFFFFu || in[2] == 0xFFFFFFFFu;
-        double fn[3] = {0, 0, 0};
-        if (need_face) {
-            double v[3][3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                for (int d = 0; d < 3; ++d) v[c][d] = a.pos[3 * (size_t)iv[c] + d];
-            double ax = v[1][0] - v[0][0], ay = v[1][1] - v[0][1], az = v[1][2] - v[0][2];
-            normalize3(ax, ay, az);
-            double bx = v[2][0] - v[1][0], by = v[2][1] - v[1][1], bz = v[2][2] - v[1][2];
-            normalize3(bx, by, bz);
-            double cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
-            normalize3(cx, cy, cz);
-            double g[4];
-            mat4_mul_vec4(nmat, cx, cy, cz, 0.0, g);
-            fn[0] = g[0]; fn[1] = g[1]; fn[2] = g[2];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (in[c] != 0xFFFFFFFFu && fused) {
-                double g[4];
-                mat4_mul_vec4(nmat, a.nrm[3 * (size_t)in[c]], a.nrm[3 * (size_t)in[c] + 1], a.nrm[3 * (size_t)in[c] + 2], 0.0, g);
-                S.n[c][0] = g[0]; S.n[c][1] = g[1]; S.n[c][2] = g[2];
-            } else if (in[c] != 0xFFFFFFFFu) {
-                S.n[c][0] = a.nout[in[c]];
-                S.n[c][1] = a.nout[(size_t)a.n_nrm + in[c]];
-                S.n[c][2] = a.nout[2 * (size_t)a.n_nrm + in[c]];
-            } else {
-                S.n[c][0] = fn[0]; S.n[c][1] = fn[1]; S.n[c][2] = fn[2];
-            }
-        }
-        uint32_t fl = 0;
-        bool has_uv = it[0] != 0xFFFFFFFFu && it[1] != 0xFFFFFFFFu && it[2] != 0xFFFFFFFFu;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            S.uv[c][0] = has_uv ? a.uvw[3 * (size_t)it[c]] : 0.0;
-            S.uv[c][1] = has_uv ? a.uvw[3 * (size_t)it[c] + 1] : 0.0;
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { S.t[d] = 0.0; S.b[d] = 0.0; }
-        if (has_uv) {
-            fl |= 1u;
-            // mod.rs:339-351; 2x2 try_inverse and the (2x2)*(2x3) product as nalgebra does them.
-            double m11 = S.uv[1][0] - S.uv[0][0], m12 = S.uv[1][1] - S.uv[0][1];
-            double m21 = S.uv[2][0] - S.uv[0][0], m22 = S.uv[2][1] - S.uv[0][1];
-            double e0[3] = {px[1] - px[0], py[1] - py[0], pz[1] - pz[0]};
-            double e1[3] = {px[2] - px[0], py[2] - py[0], pz[2] - pz[0]};
-            double det = m11 * m22 - m21 * m12;
-            if (det != 0.0) {
-                double i11 = m22 / det, i12 = -m12 / det, i21 = -m21 / det, i22 = m11 / det;
-                double t[3], b[3];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    t[d] = i12 * e1[d] + i11 * e0[d];
-                    b[d] = i22 * e1[d] + i21 * e0[d];
-                }
-                normalize4_w0(t[0], t[1], t[2]);
-                normalize4_w0(b[0], b[1], b[2]);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) { S.t[d] = t[d]; S.b[d] = b[d]; }
-                fl |= 2u;
-            }
-        }
-        S.draw = draw;
-        S.flags = fl;
+        // ---- shade record: now, or (mode bit 3) after the winner pass and only for triangles that may own a pixel
+        if (!(a.mode & 8)) a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, fused, nmat, draw);
         R.res[0] = res0;
         R.res[1] = res1;
         // Load balance of the global raster: a chunk is 64 slots.  A triangle whose scanlines are
@@ -409,7 +432,6 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
             small = true;
         }
         a.rast[seq] = R;
-        a.shade[seq] = S;
         if ((a.mode & 2) && res0) {
             if (R.flags & kTriNonFinite) {
                 int ty_lo = a.y_lo / kTile, ty_hi = (a.y_hi - 1) / kTile;
@@ -424,6 +446,9 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         }  // !out_of_band
     }
     if (a.small_flag) a.small_flag[seq] = small ? 1 : 0;  // (every draw writes it: k_small may sweep draws that do not use the path)
+    // deferred shade record: a triangle with slots always gets one (k_raster keeps no per-triangle state); one of a
+    // few pixels (k_small, the bulk of a high-polygon mesh) only if the winner pass flags it
+    if (a.mode & 8) a.need_shade[seq] = (res0 && !small) ? 1 : 0;
     if (a.mode & 1) {  // slots per half
         cnt0 = res0 && !small ? (res0 + 1u) << R.slot_shift : 0u;
         cnt1 = res1 && !small ? (res1 + 1u) << R.slot_shift : 0u;
@@ -432,6 +457,35 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
             a.half_cnt[2 * (size_t)seq + 1] = cnt1;
         }
     }
+}
+
+// Shade records after the fact (draws of many triangles, mode bit 3 of k_setup): one thread per triangle of the draw;
+// those the winner pass flagged (a sample of theirs equalled the final depth of its pixel, or they hold a NaN depth)
+// get their TriShade now, from the vertex stage evaluated per corner -- the arithmetic of k_transform, so the bits
+// are those the eager path would have written.  A 10^7-triangle mesh has a few million such triangles: the others
+// never cost 256 B of record traffic.
+__global__ __launch_bounds__(256) void k_build_shade(SetupArgs a, const uint8_t* __restrict__ need_shade) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (uint32_t)a.n_tris) return;
+    const uint32_t seq = a.tri_base + k;
+    if (!need_shade[seq]) return;
+    const uint32_t* ix = a.idx + 9 * (size_t)k;
+    const uint32_t iv[3] = {ix[0], ix[3], ix[6]};
+    const uint32_t it[3] = {ix[1], ix[4], ix[7]};
+    const uint32_t in[3] = {ix[2], ix[5], ix[8]};
+    double px[3], py[3], pz[3], vx[3], vy[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double g[4];
+        mat4_mul_vec4(a.pmv, a.pos[3 * (size_t)iv[c]], a.pos[3 * (size_t)iv[c] + 1], a.pos[3 * (size_t)iv[c] + 2], 1.0, g);
+        px[c] = g[0] / g[3];
+        py[c] = g[1] / g[3];
+        pz[c] = g[2] / g[3];
+        mat4_mul_vec4(a.vpm, px[c], py[c], pz[c], 1.0, g);  // mod.rs:320-327
+        vx[c] = g[0] / g[3];
+        vy[c] = g[1] / g[3];
+    }
+    a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, true, a.nmat, a.draw);
 }
 
 // ================================================================= (2b) scan
@@ -667,6 +721,7 @@ struct RasterArgs {
     unsigned long long* clean_state;
     uint32_t clean_words;
     NanTable* clean_nan;
+    uint8_t* need_shade;        // k_small<1>, frames with deferred shade records: [tri] = 1 if the triangle may own a pixel (else nullptr)
     // batched views (tr_render_views): triangle t belongs to view t / view_tris, whose planes start view_pix
     // pixels and whose shade blocks start view_blk blocks after the previous view's; 0 = one view
     uint32_t view_tris, view_pix, view_blk;
@@ -1106,16 +1161,21 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
 // one depth test + atomic per pixel instead of one per sample, and no scanline records at all.
 // half_live[h] (depth pass: some sample was <= the plane when it arrived) lets the winner pass skip
 // the halves that cannot hold a winner.
+// A fixed grid strides over the halves: a context that owns a band of a 10^7-triangle frame keeps a fraction of the
+// triangles, and a launch of one thread per half of the frame spent most of its time dispatching workgroups with
+// nothing to do (0.25 ms of a 1 ms band); here such a wave reads 64 flag bytes and moves on.  (A compacted LIST of
+// the small triangles, appended to by k_setup with one atomic per wave, was tried first: 160 000 atomics on one
+// counter serialise at the memory side, k_setup went from 0.6 to 1.8 ms.)
 template <int PASS, bool PRECHECK>
 __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live) {
-    const uint32_t h = a.h_lo + blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
     bool nan_active = false;
     if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
-    bool mine = h < a.h_hi;
-    if (mine) mine = a.small_flag[h >> 1] != 0;  // (a byte per triangle: the other triangles' records are not touched)
-    if (mine && PASS == 1 && a.use_live && !nan_active) mine = half_live[h] != 0;
-    if (mine) {
+    for (unsigned long long h64 = (unsigned long long)a.h_lo + blockIdx.x * blockDim.x + threadIdx.x; h64 < a.h_hi;
+         h64 += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t h = (uint32_t)h64;
+        if (a.small_flag[h >> 1] == 0) continue;  // (a byte per triangle: the other triangles' records are not touched)
+        if (PASS == 1 && a.use_live && !nan_active && half_live[h] == 0) continue;
         const uint32_t tri = h >> 1, half = h & 1u;
         const TriRaster& t = a.rast[tri];
         const uint32_t res = t.res[half];
@@ -1170,6 +1230,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                     } else if (nan_active) {
                         for (uint32_t s = 0; s < kNanSlots; ++s)
                             if (a.nan->pix[s] == pix) atomicMin((unsigned long long*)&a.nan->first_nan[s], key);
+                        if (a.need_shade) a.need_shade[tri] = 1;  // (a NaN depth wins outside the key plane)
                     }
                     continue;
                 }
@@ -1193,6 +1254,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                     // (samples come in key order: after a hit on a pixel, later ones on it cannot win)
                     if (pix != p0 && pix != p1 && a.depth[pix] == enc) {
                         atomicMin(&a.wkey[pix], key);
+                        if (a.need_shade) a.need_shade[tri] = 1;
                         a.blk_touched[2u * (blk_base + (uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW))] = 1;
                         p0 = p1;
                         p1 = pix;
@@ -1277,6 +1339,7 @@ struct ShadeArgs {
     // batched views (k_shade<false, false, true>): the grid is the views stacked in y; view v owns block rows
     // [v * view_blk_rows, (v + 1) * view_blk_rows), plane pixels from v * view_pix and draw-table entry v
     uint32_t view_blk_rows, view_pix;
+    uint32_t blk_y0;  // first block row of the launch (band contexts; 0 otherwise)
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -1379,11 +1442,13 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         }
     };
     const int x = blockIdx.x * kShadeBW + (threadIdx.x & (kShadeBW - 1));
-    const uint32_t view = VIEWS ? blockIdx.y / a.view_blk_rows : 0u;
-    const int y = (int)(blockIdx.y - view * (VIEWS ? a.view_blk_rows : 0u)) * kShadeBH + (threadIdx.x / kShadeBW);
+    // (a context that owns a band of rows launches the block rows of its band only: blk_y0 is the first of them)
+    const uint32_t by = blockIdx.y + (VIEWS ? 0u : a.blk_y0);
+    const uint32_t view = VIEWS ? by / a.view_blk_rows : 0u;
+    const int y = (int)(by - view * (VIEWS ? a.view_blk_rows : 0u)) * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
     const uint32_t pix = (VIEWS ? view * a.view_pix : 0u) + (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
-    const uint32_t blk = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t blk = by * gridDim.x + blockIdx.x;
     if (a.skip_clean) {
         // Nothing landed in this block: its keys are all "none".  If the previous frame left it
         // at the background colour too there is nothing to do; otherwise repaint the background.
@@ -1422,7 +1487,7 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     bool has = key != kKeyNone;
     unsigned long long nwin = __popcll(__ballot(has));
     if ((threadIdx.x & 63) == 0 && nwin)
-        atomicAdd(&a.cov_counters[(size_t)(((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8], nwin);
+        atomicAdd(&a.cov_counters[(size_t)((blk * 4 + (threadIdx.x >> 6)) % kCounterSlots) * 8], nwin);
     {
         static_assert(kShadeBW * kShadeBH == 64, "the shade workgroup is one wave: votes instead of barriers");
         const bool any = nwin != 0ull;
