@@ -64,6 +64,144 @@ def cpu_baseline(W, H, draws, budget_s=12.0):
             "ms_per_frame": med * 1e3, "fragments_per_frame": st.counters()["fragments"]}
 
 
+def secondary_bands(torch, dist, rank, world, device, frames=6, warm=3):
+    """BASELINE.json configs[3]: african_head subdivided 6x (10 207 232 triangles) at 7680x4320, ONE frame cut into
+    tile-row bands, one per rank (tr_set_band), re-cut every frame from the ranks' last band times (one all-gather
+    of a float each, sharding.rebalance); the RGBA8 bands go to rank 0 straight from the contexts' device memory
+    (sharding.device_frames -> dist.gather: RCCL over xGMI).  frames/s = 1 / (slowest rank's render + the gather)."""
+    import big_cases as B
+    from tinyrenderer_amd import _ffi, sharding
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    levels = int(os.environ.get("TR_BENCH_BANDS_LEVELS", "6"))
+    W, H, draws = B.head_subdivided(levels, 7680, 4320)
+    st = ModelRendererState(W, H, device=device)
+    plane = sharding.device_frames(st)[0]
+    on_gpu = world == 1 or dist.get_backend() == "nccl"
+    bands = [sharding.band_rows(H, r, world) for r in range(world)]
+    per_frame, renders, full = [], [], None
+    for it in range(warm + frames):
+        y_lo, y_hi = bands[rank]
+        if world > 1:
+            dist.barrier()
+        st.synchronize()
+        t0 = time.perf_counter()
+        clear_screen(st)
+        st.set_band(y_lo, y_hi)
+        render_mesh_component(st, *draws[0])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        st.synchronize()
+        t_render = (time.perf_counter() - t0) * 1e3
+        sharding.to_torch(st)
+        full = sharding.gather_bands(plane[y_lo:y_hi], H, dst=0, spans=bands)
+        torch.cuda.synchronize()
+        sharding.to_renderer(st)
+        if world > 1:
+            dist.barrier()
+        t_frame = (time.perf_counter() - t0) * 1e3
+        times = [t_render]
+        if world > 1:
+            t = torch.tensor([t_render], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            out = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            times = [float(x.item()) for x in out]
+        if it >= warm:
+            per_frame.append(t_frame)
+            renders.append(times)
+        if world > 1:
+            bands = sharding.rebalance(bands, times, H)
+    rec = {"workload": f"african_head subdivided {levels}x ({draws[0][0].mesh.triangles.shape[0]} triangles) {W}x{H}, "
+                       f"{world} tile-row band(s), RGBA8 gather to rank 0 (BASELINE.json configs[3])",
+           "frames_per_s": 1e3 / float(np.median(per_frame)), "ms_per_frame": float(np.median(per_frame)),
+           "render_ms_per_rank_last_frame": [round(x, 3) for x in renders[-1]], "band_rows_last_frame": [hi - lo for lo, hi in bands]}
+    if rank == 0 and levels == 6:
+        import hashlib
+
+        want = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["c4_head_sub6_8k"]["rgba8"]
+        img = full.cpu().numpy().view(np.uint8).reshape(H, W, 4)[::-1]  # (the plane is not flipped)
+        rec["verified"] = hashlib.sha256(np.ascontiguousarray(img)).hexdigest() == want
+    st.close()
+    return rec
+
+
+def secondary_orbit(torch, dist, rank, world, device, n_total=4096):
+    """BASELINE.json configs[4]: the 4096-view camera orbit of diablo3_pose at 1920x1080, a contiguous block of
+    views per rank (sharding.shard_range), rendered in batches through tr_render_views; views/s of the whole job
+    with the frames left resident in each rank's HBM, and with every batch delivered to rank 0 (dist.gather from
+    the contexts' device memory)."""
+    import scene_util as SU
+    from tinyrenderer_amd import _ffi, scenes, sharding
+    from tinyrenderer_amd.model_renderer import ModelRendererState, make_draw_params
+
+    W, H = 1920, 1080
+    batch = int(os.environ.get("TR_BENCH_ORBIT_BATCH", "16"))
+    n_ctx = int(os.environ.get("TR_BENCH_ORBIT_CONTEXTS", "4"))
+    n_total = int(os.environ.get("TR_BENCH_ORBIT_VIEWS", str(n_total)))
+    mc = SU.component("diablo")
+    mc.transform.set_rotation((0.0, 0.0, 0.0))
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    n_local = hi - lo
+    lib = _ffi.load()
+    states = [ModelRendererState(W, H, device=device, max_views=batch) for _ in range(n_ctx)]
+    shaders = [scenes.shader_for(mc, W, H, eye=scenes.orbit_eye(k, n_total)) for k in range(lo, hi)]  # host, once (SURVEY.md 8(d))
+    params, meshes = [], []
+    for s_ in states:
+        arr = (_ffi.DrawParams * max(1, n_local))()
+        for k, sh in enumerate(shaders):
+            arr[k] = make_draw_params(s_, sh, mc.texture, mc.normal_map)
+        params.append(arr)
+        meshes.append(s_._mesh_handle(mc.mesh))
+    stride = C.sizeof(_ffi.DrawParams)
+    max_local = max(sharding.shard_range(n_total, r, world)[1] - sharding.shard_range(n_total, r, world)[0] for r in range(world))
+    planes = [sharding.device_frames(s_, batch) for s_ in states]
+    on_gpu = world == 1 or dist.get_backend() == "nccl"
+    recv = None
+    if rank == 0 and world > 1:
+        recv = [torch.empty((batch, H, W), dtype=torch.int32, device="cuda" if on_gpu else "cpu") for _ in range(world)]
+
+    def run(deliver):
+        done, i = 0, 0
+        while done < max_local:  # (every rank makes the same number of gather calls)
+            v = max(0, min(batch, n_local - done))
+            s_ = states[i % n_ctx]
+            if v:
+                p = C.cast(C.byref(params[i % n_ctx], done * stride), C.POINTER(_ffi.DrawParams))
+                rc = lib.tr_render_views(s_._ctx, meshes[i % n_ctx], p, v, _ffi.TR_OUT_RGBA8)
+                if rc != 0:
+                    _ffi.check(s_._ctx, rc, "tr_render_views")
+            if deliver and world > 1:
+                sharding.to_torch(s_)
+                src = planes[i % n_ctx] if on_gpu else planes[i % n_ctx].cpu()
+                dist.gather(src, recv, dst=0)
+                sharding.to_renderer(s_)
+            done += batch
+            i += 1
+        for s_ in states:
+            s_.synchronize()
+        torch.cuda.synchronize()
+
+    def timed(deliver):
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        run(deliver)
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0
+
+    run(False)
+    t_res = min(timed(False) for _ in range(2))
+    t_del = min(timed(True) for _ in range(2)) if world > 1 else t_res
+    frags = states[0].counters()["fragments"]
+    rec = {"workload": f"diablo3_pose {W}x{H}, {n_total}-view orbit, {world} rank(s) x {n_local} views, batches of {batch} views "
+                       f"(tr_render_views) on {n_ctx} contexts (BASELINE.json configs[4])",
+           "views_per_s_resident": n_total / t_res, "views_per_s_delivered_to_rank0": n_total / t_del,
+           "fragments_last_batch_context0": frags}
+    for s_ in states:
+        s_.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +212,8 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[3] (bands) and configs[4] (orbit) records beside the headline line")
     ap.add_argument("--profile-frames", type=int, default=30)
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("TR_BENCH_CONTEXTS", "4")),
                     help="render contexts (HIP streams) used round-robin: frames of successive steps overlap")
@@ -250,6 +390,14 @@ def main():
         out["cpu_baseline"] = cpu_baseline(W, H, draws)
     for s_ in states:
         s_.close()
+    # ---- the other two multi-GPU configurations of BASELINE.json, beside the headline (never part of `value`)
+    if not args.no_secondary:
+        out["secondary"] = {}
+        for name, fn in (("bands_8k_10M_triangles", secondary_bands), ("orbit_4096_views_1080p", secondary_orbit)):
+            try:
+                out["secondary"][name] = fn(torch, dist, rank, world, local_rank)
+            except Exception as e:  # (a failure here must not cost the headline line)
+                out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         v = torch.tensor([0 if verified is False else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(v, op=dist.ReduceOp.MIN)

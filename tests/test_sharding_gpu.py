@@ -1,0 +1,100 @@
+"""The N>1 DATA path with real GPU frames, two ranks on ONE device (gloo; RCCL refuses two ranks on a device): every
+rank renders its tile-row band (tr_set_band) / its block of views (tr_render_views), hands the context's device plane
+to torch without a copy (sharding.device_frames over tr_device_ptr_rgba8, streams ordered by to_torch / to_renderer),
+and the single delivery gather stitches them on rank 0, where they must equal the whole frame rendered by one
+context and the oracle's frames."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(W, H):
+    import scene_util as SU
+    from tinyrenderer_amd import scenes
+
+    head = SU.component("head")
+    head.transform.set_rotation((0.025, 0.0, 0.0))
+    return head, scenes.shader_for(head, W, H)
+
+
+def _worker(rank, world, port, W, H, n_views, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import scene_util as SU
+        from tinyrenderer_amd import _ffi, scenes, sharding
+        from tinyrenderer_amd.model_renderer import (ModelRendererState, clear_screen, render_mesh_component,
+                                                     render_views)
+
+        # ---- bands of one frame, two frames in a row with the bands re-cut in between
+        head, sh = _scene(W, H)
+        st = ModelRendererState(W, H, device=0)
+        plane = sharding.device_frames(st)[0]  # (H, W) int32, the context's own memory
+        fulls = []
+        bands = [sharding.band_rows(H, r, world) for r in range(world)]
+        for frame in range(2):
+            y_lo, y_hi = bands[rank]
+            clear_screen(st)
+            st.set_band(y_lo, y_hi)
+            render_mesh_component(st, head, sh)
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            sharding.to_torch(st)
+            full = sharding.gather_bands(plane[y_lo:y_hi], H, dst=0, spans=bands)
+            sharding.to_renderer(st)
+            fulls.append(None if full is None else full.cpu().numpy())
+            bands = sharding.rebalance(bands, [1.0 + r for r in range(world)], H)  # (any new cut will do here)
+        st.close()
+        # ---- a block of views per rank, rendered as one batch, gathered in view order
+        mc = SU.component("diablo")
+        mc.transform.set_rotation((0.0, 0.0, 0.0))
+        lo, hi = sharding.shard_range(n_views, rank, world)
+        vs = ModelRendererState(W, H, device=0, max_views=max(2, hi - lo))
+        shaders = [scenes.shader_for(mc, W, H, eye=scenes.orbit_eye(k, n_views)) for k in range(lo, hi)]
+        render_views(vs, mc, shaders, _ffi.TR_OUT_RGBA8)
+        sharding.to_torch(vs)
+        frames = sharding.gather_frames(sharding.device_frames(vs, hi - lo), n_views, dst=0)
+        sharding.to_renderer(vs)
+        vs.close()
+        if rank == 0:
+            np.savez(out_path, full0=fulls[0], full1=fulls[1], frames=frames.cpu().numpy())
+        else:
+            assert frames is None and fulls == [None, None]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_real_gpu_bands_and_views_stitch_to_the_whole_frame(oracle, tmp_path):
+    import scene_util as SU
+    from tinyrenderer_amd import scenes
+
+    W, H, n_views = 320, 208, 5
+    out_path = str(tmp_path / "out.npz")
+    mp.start_processes(_worker, args=(2, _free_port(), W, H, n_views, out_path), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out_path)
+    head, sh = _scene(W, H)
+    whole = SU.gpu_render(W, H, [(head, sh)])["present"]  # one context, no band
+    o = SU.oracle_render(oracle, W, H, [(head, sh)])["present"]
+    assert np.array_equal(whole, o)
+    for name in ("full0", "full1"):  # the device plane is not flipped: row 0 = bottom
+        assert np.array_equal(got[name].view(np.uint8).reshape(H, W, 4)[::-1], whole), name
+    mc = SU.component("diablo")
+    mc.transform.set_rotation((0.0, 0.0, 0.0))
+    for k in range(n_views):
+        want = SU.oracle_render(oracle, W, H, [(mc, scenes.shader_for(mc, W, H, eye=scenes.orbit_eye(k, n_views)))])["present"]
+        assert np.array_equal(got["frames"][k].view(np.uint8).reshape(H, W, 4)[::-1], want), k

@@ -51,6 +51,80 @@ def balanced_bands(tile_row_weights, world, tile=TILE, height=None):
     return [(min(a * tile, height), min(b * tile, height)) for a, b in zip(cuts[:-1], cuts[1:])]
 
 
+def rebalance(bands, times_ms, height, tile=TILE):
+    """Next frame's bands from this frame's: `times_ms[r]` is how long rank r's band took (what every rank learns
+    from one all-gather of a float).  The cost per tile row is taken constant inside a band after removing a fixed
+    share, `balanced_bands` equalises it, and every cut moves half of the way (damping)."""
+    world = len(bands)
+    n_rows = (height + tile - 1) // tile
+    fixed = 0.5 * min(times_ms)  # rough share of a band's time that does not depend on its rows
+    row_w = [0.0] * n_rows
+    for (y_lo, y_hi), t in zip(bands, times_ms):
+        k0, k1 = y_lo // tile, (y_hi + tile - 1) // tile
+        for k in range(k0, k1):
+            row_w[k] = max(t - fixed, 1e-3) / max(1, k1 - k0)
+    proposed = balanced_bands(row_w, world, tile=tile, height=height)
+    cuts = [0] + [((a[1] + b[1]) // 2) // tile * tile for a, b in zip(bands[:-1], proposed[:-1])] + [height]
+    for i in range(1, len(cuts)):  # (keep every band non-empty while rows remain)
+        cuts[i] = max(cuts[i], min(cuts[i - 1] + tile, height))
+    cuts[-1] = height
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+# ---- the renderer's planes as torch tensors, without a copy ---------------------------------------------------
+class _DevicePlane:
+    """`__cuda_array_interface__` over the context's RGBA8 plane (tr_device_ptr_rgba8): torch wraps the memory
+    in place.  The state must outlive every tensor made from it."""
+
+    def __init__(self, state, n_views):
+        import ctypes as C
+
+        from . import _ffi
+
+        p = C.c_void_p()
+        if n_views > 1:
+            state.select_view(0)  # (the slices are contiguous in view order from view 0's address)
+        _ffi.check(state._ctx, state._lib.tr_device_ptr_rgba8(state._ctx, C.byref(p)), "tr_device_ptr_rgba8")
+        self._keep = state
+        self.__cuda_array_interface__ = {"shape": (n_views, state.frame_height, state.frame_width), "typestr": "<i4",
+                                         "data": (int(p.value), False), "version": 2, "strides": None}
+
+
+def device_frames(state, n_views=1, device=None):
+    """(n_views, H, W) int32 tensor (packed RGBA8, row 0 = bottom: the plane is not flipped) that IS the context's
+    device memory.  Order the streams with `to_torch` / `to_renderer` around its use."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return torch.as_tensor(_DevicePlane(state, n_views), device=dev)
+
+
+def render_stream(state):
+    """The context's HIP stream (tr_get_stream) as a torch stream."""
+    import ctypes as C
+
+    from . import _ffi
+
+    p = C.c_void_p()
+    _ffi.check(state._ctx, state._lib.tr_get_stream(state._ctx, C.byref(p)), "tr_get_stream")
+    return torch.cuda.ExternalStream(int(p.value))
+
+
+def to_torch(state):
+    """torch's current stream waits for everything the renderer has queued (before a collective reads its planes)."""
+    torch.cuda.current_stream().wait_stream(render_stream(state))
+
+
+def to_renderer(state):
+    """The renderer's stream waits for torch's current stream (before the next frame overwrites the planes)."""
+    render_stream(state).wait_stream(torch.cuda.current_stream())
+
+
+def _stage(t):
+    """gloo moves host memory: device tensors (rehearsals of several ranks on one GPU) go through the host."""
+    if dist.is_initialized() and dist.get_backend() == "gloo" and t.is_cuda:
+        return t.cpu()
+    return t
+
+
 def gather_frames(local, n_total, dst=0):
     """Gather per-rank blocks of finished frames (n_local, H, W) uint8/int32 onto `dst` in view
     order.  Returns the (n_total, H, W) tensor on dst, None elsewhere."""
@@ -58,6 +132,7 @@ def gather_frames(local, n_total, dst=0):
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return local
+    local = _stage(local)
     max_n = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
     pad = torch.zeros((max_n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
@@ -80,6 +155,7 @@ def gather_bands(local_band, height, dst=0, tile=TILE, spans=None):
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return local_band
+    local_band = _stage(local_band)
     spans = [band_rows(height, r, world, tile) for r in range(world)] if spans is None else list(spans)
     max_rows = max(hi - lo for lo, hi in spans)
     pad = torch.zeros((max_rows,) + tuple(local_band.shape[1:]), dtype=local_band.dtype, device=local_band.device)
