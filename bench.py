@@ -280,7 +280,8 @@ def main():
     sync()
     counters = st.counters()
     flags = st.status_flags()
-    assert flags == 0, f"status flags {flags:#x}"
+    no_verify = os.environ.get("TR_BENCH_NO_VERIFY") == "1"  # (timing experiments with kernels that draw wrong pixels: tools/ab_bench.sh)
+    assert flags == 0 or no_verify, f"status flags {flags:#x}"
 
     barrier()
     sync()
@@ -303,7 +304,7 @@ def main():
     # counters and covered pixels against the oracle's digest of this frame (made in the build container by
     # tests/golden/make_golden.py --big; the oracle itself is timed below as cpu_baseline)
     verified = None
-    if (W, H) == (3840, 2160):
+    if (W, H) == (3840, 2160) and not no_verify:
         import hashlib
 
         want = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["c3_head_4k"]

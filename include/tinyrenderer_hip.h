@@ -280,7 +280,7 @@ const char* tr_load_error(void);
 
 /* Device self-test of the exact arithmetic shortcuts the kernels use (no counterpart in the reference):
  * runs them against the operations they stand for on about n_values pseudo-random operands.
- * out[0] reserved (0), out[1] x/255 as multiply + fmas vs `/`, out[2] pixel
+ * out[0] the hardware's saturating f64 -> u32 conversion vs Rust's `as` rule, out[1] x/255 as multiply + fmas vs `/`, out[2] pixel
  * rounding vs round(): numbers of mismatches (all must be 0); out[3] operands tried per check. */
 int tr_selftest_arithmetic(int device, uint64_t n_values, uint64_t seed, uint64_t out[4]);
 

@@ -120,8 +120,9 @@ __device__ __forceinline__ double dot3(double ax, double ay, double az, double b
     double p0 = ax * bx, p1 = ay * by, p2 = az * bz;
     return (p0 + p1) + p2;
 }
+// (nalgebra's norm folds from 0.0: `0.0 + s` is s bit for bit here, s being a sum of squares and so never -0)
 __device__ __forceinline__ void normalize3(double& x, double& y, double& z) {
-    double n = sqrt(0.0 + dot3(x, y, z, x, y, z));
+    const double n = sqrt(dot3(x, y, z, x, y, z));
     x = x / n;
     y = y / n;
     z = z / n;
@@ -131,7 +132,7 @@ __device__ __forceinline__ void normalize4_w0(double& x, double& y, double& z) {
     double p0 = x * x, p1 = y * y, p2 = z * z, p3 = 0.0 * 0.0;
     p0 += p2;
     p1 += p3;
-    double n = sqrt(0.0 + (p0 + p1));
+    const double n = sqrt(p0 + p1);
     x = x / n;
     y = y / n;
     z = z / n;
@@ -211,6 +212,24 @@ struct __attribute__((aligned(64))) ScanRec {
 static_assert(sizeof(ScanRec) == 64, "ScanRec must be 64 B");
 constexpr unsigned long long kRecHresMask = 0x3FFFFull;
 
+
+// Rust `v as u8` (and `v as usize`, as far as 32 bits): truncation toward zero, NaN and negatives to 0, saturation
+// above -- which is what the hardware conversion does by itself (the C++ cast is undefined out of range, so the
+// instruction is named).  tr_selftest_arithmetic compares it with the spelled-out rule.
+__device__ __forceinline__ uint32_t f64_as_u32_sat(double v) {
+    uint32_t r;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ uint32_t f64_as_u8(double v) {
+    const uint32_t r = f64_as_u32_sat(v);
+    return r < 255u ? r : 255u;
+}
+__device__ __forceinline__ uint32_t f64_as_u8_spelled_out(double v) {
+    if (!(v > 0.0)) return 0u;  // NaN, negative, zero
+    if (v >= 255.0) return 255u;
+    return (uint32_t)v;
+}
 
 // x / 255.0, correctly rounded, in 3 operations instead of the ~11 of a general f64 division.
 // With r = RN(1/255): q = RN(x r), e = x - 255 q (exact in an fma: a multiple of ulp(q) below

@@ -1346,9 +1346,9 @@ struct ShadeArgs {
 __device__ __forceinline__ void sample_rgb(const uint32_t* __restrict__ img, int W, int H, double x,
                                            double y, double out[3], uint32_t* flags) {
     double x1 = floor(x), y1 = floor(y);
-    // `x1 as usize`: NaN / negative -> 0, saturating above
-    uint32_t ix1 = (x1 > 0.0) ? (x1 >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)x1) : 0u;
-    uint32_t iy1 = (y1 > 0.0) ? (y1 >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)y1) : 0u;
+    // `x1 as usize`: NaN / negative -> 0, saturating above (any index >= 2^32 - 1 is out of range either way)
+    uint32_t ix1 = f64_as_u32_sat(x1);
+    uint32_t iy1 = f64_as_u32_sat(y1);
     uint32_t ix2 = ix1 == 0xFFFFFFFFu ? ix1 : ix1 + 1u;
     uint32_t iy2 = iy1 == 0xFFFFFFFFu ? iy1 : iy1 + 1u;
     if (ix2 > (uint32_t)(W - 1)) ix2 = (uint32_t)(W - 1);
@@ -1398,12 +1398,6 @@ __device__ __forceinline__ DrawDev uniform_drawdev(const DrawDev* p) {  // (p is
     return u.d;
 }
 
-// Rust `v as u8`
-__device__ __forceinline__ uint32_t f64_as_u8(double v) {
-    if (!(v > 0.0)) return 0u;  // NaN, negative, zero
-    if (v >= 255.0) return 255u;
-    return (uint32_t)v;
-}
 
 
 // x^e of the extension shaders' specular term.  A specular MAP holds bytes, so the exponent is almost
@@ -1671,7 +1665,8 @@ __global__ __launch_bounds__(256) void k_clear_state(unsigned long long* state_b
 
 // ============================================================ arithmetic self-test
 // The exact shortcuts of tr_device.h against the operations they stand for, on the device:
-// [0] reserved (0), [1] div255 vs `/ 255.0`, [2] pixel_coord vs round(), [3] values tried per check.
+// [0] the hardware's saturating f64 -> u32 conversion vs the spelled-out `as u8` / `as usize` rule,
+// [1] div255 vs `/ 255.0`, [2] pixel_coord vs round(), [3] values tried per check.
 __device__ __forceinline__ unsigned long long st_next(unsigned long long& s) {
     s ^= s << 13; s ^= s >> 7; s ^= s << 17;
     return s;
@@ -1708,6 +1703,12 @@ __global__ __launch_bounds__(256) void k_selftest(unsigned long long seed, uint3
         const unsigned long long t = st_next(s);
         const double mix = (double)(t & 255) * ((1.0 - fx) * (1.0 - fy)) + (double)((t >> 8) & 255) * (fx * (1.0 - fy)) +
                            (double)((t >> 16) & 255) * ((1.0 - fx) * fy) + (double)((t >> 24) & 255) * (fx * fy);
+        {   // the hardware's saturating conversions against the spelled-out rule
+            const double cv = (it & 3) == 0 ? mix : ((it & 3) == 1 ? num : st_double(s, 12));
+            bad0 += f64_as_u8(cv) != f64_as_u8_spelled_out(cv) ? 1 : 0;
+            const uint32_t want = (cv > 0.0) ? (cv >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)cv) : 0u;
+            bad0 += f64_as_u32_sat(cv) != want ? 1 : 0;
+        }
         bad1 += differ(div255(mix), mix / 255.0) ? 1 : 0;
         bad1 += differ(div255(num), num / 255.0) ? 1 : 0;
         // pixel coordinates: around half-integers and anywhere

@@ -5,7 +5,7 @@
 R=$1; CTX=$2; shift 2
 for i in $(seq 1 "$R"); do
   for lib in "$@"; do
-    TINYRENDERER_HIP_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --contexts "$CTX" --steps 600 --warmup 50 --no-cpu-baseline > /tmp/ab.json 2>/tmp/ab.err || { cat /tmp/ab.err; exit 1; }
+    TR_BENCH_NO_VERIFY=${NO_VERIFY:-0} TINYRENDERER_HIP_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --contexts "$CTX" --steps 6 --warmup 1 --no-cpu-baseline --no-secondary > /tmp/ab.json 2>/tmp/ab.err || { cat /tmp/ab.err; exit 1; }
     python3 -c "
 import json,sys
 d=json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1])
