@@ -44,6 +44,7 @@ struct tr_mesh {
     double* nrm = nullptr;
     double* uvw = nullptr;
     uint32_t* idx = nullptr;
+    double* bounds = nullptr;  // meshes of 65 536 triangles or more: a box per 64 consecutive triangles (k_mesh_bounds)
     int64_t n_pos = 0, n_nrm = 0, n_uvw = 0, n_tris = 0;
     bool any_uv = false;
 };
@@ -92,6 +93,7 @@ struct tr_context {
     uint32_t* flip_buf = nullptr;    // tr_read_rgba8(flip): the presented image, flipped on the device
     uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
+    uint8_t* small_grp = nullptr;    // per 32 triangles: some triangle of the group is small (tri_cap / 32 + 1 bytes)
     uint8_t* need_shade = nullptr;   // deferred shade records: per triangle, flagged by the winner pass (tri_cap bytes)
     uint32_t defer_tris = 65536;     // draws with at least this many triangles defer their shade records (TR_DEFER_SHADE)
     struct Deferred { const tr_mesh* mesh; SetupArgs sa; };
@@ -233,7 +235,9 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     TriRaster* nr = nullptr;
     TriShade* ns = nullptr;
     uint32_t *ncnt = nullptr, *noff = nullptr;
-    uint8_t *nlive = nullptr, *nsmall = nullptr, *nneed = nullptr;
+    uint8_t *nlive = nullptr, *nsmall = nullptr, *nneed = nullptr, *ngrp = nullptr;
+    TR_HIP(c, hipMalloc(&ngrp, cap / 32 + 1));
+    TR_HIP(c, hipMemsetAsync(ngrp, 0, cap / 32 + 1, c->stream));
 
     TR_HIP(c, hipMalloc(&nneed, cap));
     TR_HIP(c, hipMalloc(&nlive, 2 * cap));
@@ -252,6 +256,7 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
         TR_HIP(c, hipMemcpyAsync(nlive, c->half_live, 2 * n, hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(nsmall, c->small_flag, n, hipMemcpyDeviceToDevice, c->stream));
         TR_HIP(c, hipMemcpyAsync(nneed, c->need_shade, n, hipMemcpyDeviceToDevice, c->stream));
+        TR_HIP(c, hipMemcpyAsync(ngrp, c->small_grp, n / 32 + 1, hipMemcpyDeviceToDevice, c->stream));
     } else if (c->half_off) {
         TR_HIP(c, hipMemcpyAsync(noff, c->half_off, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
     } else {
@@ -259,7 +264,8 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
     }
     TR_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt); (void)hipFree(c->half_off);
-    (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade);
+    (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->small_grp);
+    c->small_grp = ngrp;
     c->rast = nr; c->shade = ns; c->half_cnt = ncnt; c->half_off = noff; c->half_live = nlive; c->small_flag = nsmall;
     c->need_shade = nneed;
     c->tri_cap = cap;
@@ -305,6 +311,7 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.half_off = c->half_off;
     ra.rast = c->rast;
     ra.small_flag = c->small_flag;
+    ra.small_grp = c->small_grp;
     ra.rec = c->rec;
     ra.rec_cap = c->rec_cap;
     ra.depth = c->depth;
@@ -783,7 +790,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->small_grp); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -846,6 +853,8 @@ int tr_clear(tr_context* c) {
     c->frame_lost_texture = false;
     c->deferred.clear();
     c->frame_lost_mesh = false;
+    if (c->small_any)  // the per-group summary of the small triangles restarts with the frame
+        TR_HIP(c, hipMemsetAsync(c->small_grp, 0, c->tri_cap / 32 + 1, c->stream));
     c->small_any = false;
     c->view_tris = 0;
     c->n_views = c->max_views;  // (an empty frame resolves every slice)
@@ -891,6 +900,17 @@ int tr_mesh_create(tr_context* c, const double* positions, int64_t n_positions, 
     if (e == hipSuccess) e = up((void**)&m->nrm, normals, (size_t)n_normals * 3 * sizeof(double));
     if (e == hipSuccess) e = up((void**)&m->uvw, uvw, (size_t)n_uvw * 3 * sizeof(double));
     if (e == hipSuccess) e = up((void**)&m->idx, idx, (size_t)n_triangles * 9 * sizeof(uint32_t));
+    if (e == hipSuccess && n_triangles >= 65536) {
+        // cluster boxes for band contexts (multi-GPU): one pass over the mesh, here rather than per frame
+        const uint32_t n_clusters = (uint32_t)((n_triangles + 63) / 64);
+        e = hipMalloc(&m->bounds, (size_t)n_clusters * 6 * sizeof(double));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_mesh_bounds, dim3((n_clusters + 255) / 256), dim3(256), 0, c->stream, m->idx, m->pos,
+                               (uint32_t)n_triangles, m->bounds);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
     if (e != hipSuccess) {
         tr_mesh_destroy(c, m);
         return fail(c, e == hipErrorOutOfMemory ? TR_ERR_OOM : TR_ERR_HIP, hipGetErrorString(e));
@@ -907,7 +927,7 @@ int tr_mesh_destroy(tr_context* c, tr_mesh* m) {
     // a draw whose shade records are built at resolve time (large draws) reads the mesh again then
     for (const auto& d : c->deferred)
         if (d.mesh == m) c->frame_lost_mesh = true;
-    (void)hipFree(m->pos); (void)hipFree(m->nrm); (void)hipFree(m->uvw); (void)hipFree(m->idx);
+    (void)hipFree(m->pos); (void)hipFree(m->nrm); (void)hipFree(m->uvw); (void)hipFree(m->idx); (void)hipFree(m->bounds);
     delete m;
     return TR_OK;
 }
@@ -1094,7 +1114,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
         sa.small_res = 0;
-        sa.small_flag = c->small_flag;
+        sa.small_flag = c->small_flag; sa.small_grp = c->small_grp;
         sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;  // (the row raster uses the global raster's slot sequence)
         if (c->mode == 0 && c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
             sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots
@@ -1104,6 +1124,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.need_shade = c->need_shade;
         if (defer) sa.mode |= 8;  // no TriShade now: k_build_shade writes it for the triangles the winner pass flags
         sa.per_corner = defer ? 1 : 0;
+        sa.bounds = mesh->bounds;
         DrawDev& d = sa.params;
         fill_draw_dev(d, p);
         sa.draw_table = c->draw_table;
@@ -1220,7 +1241,7 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
         sa.vpm = viewport_matrix(c->W, c->H);
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
-        sa.small_flag = c->small_flag;
+        sa.small_flag = c->small_flag; sa.small_grp = c->small_grp;
         sa.y_lo = 0; sa.y_hi = c->H; sa.mode = 1;
         if (c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
             sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots

@@ -61,6 +61,7 @@ struct SetupArgs {
                            // bit3: no TriShade now (k_build_shade writes it for the triangles the winner pass flags)
     uint32_t small_res;    // a triangle is small if neither half has more than small_res + 1 scanlines
     uint8_t* small_flag;   // per triangle: 1 = flagged kTriSmall (what k_small reads)
+    uint8_t* small_grp;    // per 32 triangles: raised if one of them is small (k_small skips the other groups)
     uint8_t* need_shade;   // per triangle, draws with deferred shade records (mode bit 3): zeroed here, set by the winner pass
     uint32_t* flags;
     DrawDev params;
@@ -78,6 +79,8 @@ struct SetupArgs {
     const ViewDev* views;
     uint32_t n_views;
     int per_corner;        // k_setup<false, false>: evaluate the vertex stage per corner instead of reading ndc / nout
+    const double* bounds;  // per 64 consecutive triangles of the mesh: min xyz, max xyz of their positions (k_mesh_bounds),
+                           // or nullptr; a context that owns a band drops whole clusters that project outside its rows
 };
 
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
@@ -108,6 +111,42 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) a.draw_table[a.draw] = a.params;
     uint32_t c0 = 0, c1 = 0;  // slots of my triangle's two halves
+    if (!FUSED && a.bounds && a.per_corner && (a.y_lo > 0 || a.y_hi < a.H)) {
+        // Band contexts (multi-GPU): the wave's 64 triangles are one cluster of the mesh.  Lanes 0..7 take the corners
+        // of its bounding box through the vertex stage and the viewport; with w > 0 at all eight the projection of
+        // everything inside the box lies between the corners' extremes, so a box that misses the band's rows by more
+        // than a pixel of margin holds no triangle that could land a sample there: the wave writes "nothing" for its
+        // triangles without reading one index or position (7/8 of a 10^7-triangle mesh on an 8-GPU node).
+        const int lane = threadIdx.x & 63;
+        const double* b = a.bounds + 6 * (size_t)((uint32_t)k >> 6);
+        double y = 0.0;
+        bool ok = true;
+        if (lane < 8 && (k - lane) < a.n_tris) {
+            double g[4], v[4];
+            mat4_mul_vec4(a.pmv, b[(lane & 1) ? 3 : 0], b[(lane & 2) ? 4 : 1], b[(lane & 4) ? 5 : 2], 1.0, g);
+            mat4_mul_vec4(a.vpm, g[0] / g[3], g[1] / g[3], g[2] / g[3], 1.0, v);
+            y = v[1] / v[3];
+            ok = g[3] > 1e-12 && fabs(y) < 1e15;  // (NaN fails both)
+        }
+        double ymin = y, ymax = y;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            ymin = fmin(ymin, __shfl_xor(ymin, d, 64));
+            ymax = fmax(ymax, __shfl_xor(ymax, d, 64));
+        }
+        const bool all_ok = (__ballot(ok) & 0xFFull) == 0xFFull;
+        const bool miss = ceil(ymin - 1.5) > (double)(a.y_hi - 1) || floor(ymax + 1.5) < (double)a.y_lo;
+        const bool skip = all_ok && __shfl((int)miss, 0, 64) != 0;
+        if (skip) {
+            if (k < a.n_tris) {
+                const uint32_t seq = a.tri_base + (uint32_t)k;
+                if (a.mode & 1) *reinterpret_cast<uint2*>(a.half_cnt + 2 * (size_t)seq) = make_uint2(0u, 0u);
+                if (a.small_flag) a.small_flag[seq] = 0;
+                if (a.mode & 8) a.need_shade[seq] = 0;
+            }
+            return;
+        }
+    }
     if (k < a.n_tris) {
         // (per_corner: a draw whose shade records are deferred needs no normals here and its positions once per
         // corner: the vertex stage is evaluated in place, there is no k_transform launch and no ndc array)
@@ -446,6 +485,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         }  // !out_of_band
     }
     if (a.small_flag) a.small_flag[seq] = small ? 1 : 0;  // (every draw writes it: k_small may sweep draws that do not use the path)
+    if (small) a.small_grp[seq >> 5] = 1;  // (zeroed by tr_clear; lanes of a group store the same byte)
     // deferred shade record: a triangle with slots always gets one (k_raster keeps no per-triangle state); one of a
     // few pixels (k_small, the bulk of a high-polygon mesh) only if the winner pass flags it
     if (a.mode & 8) a.need_shade[seq] = (res0 && !small) ? 1 : 0;
@@ -488,6 +528,35 @@ __global__ __launch_bounds__(256) void k_build_shade(SetupArgs a, const uint8_t*
     a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, true, a.nmat, a.draw);
 }
 
+// Bounding boxes of the mesh's clusters of 64 consecutive triangles (object space), once per mesh (tr_mesh_create):
+// bounds[6 c .. 6 c + 5] = min x, y, z, max x, y, z over the positions the cluster's triangles index.
+__global__ __launch_bounds__(256) void k_mesh_bounds(const uint32_t* __restrict__ idx, const double* __restrict__ pos,
+                                                     uint32_t n_tris, double* __restrict__ bounds) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t0 = c * 64u;
+    if (t0 >= n_tris) return;
+    const uint32_t t1 = t0 + 64u < n_tris ? t0 + 64u : n_tris;
+    double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
+    double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
+    bool bad = false;
+    for (uint32_t t = t0; t < t1; ++t)
+        for (int cnr = 0; cnr < 3; ++cnr) {
+            const uint32_t v = idx[9 * (size_t)t + 3 * cnr];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double p = pos[3 * (size_t)v + d];
+                bad = bad || !(fabs(p) < __builtin_huge_val());
+                lo[d] = fmin(lo[d], p);
+                hi[d] = fmax(hi[d], p);
+            }
+        }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // (a non-finite position: a box nothing is culled against)
+        bounds[6 * (size_t)c + d] = bad ? __builtin_nan("") : lo[d];
+        bounds[6 * (size_t)c + 3 + d] = bad ? __builtin_nan("") : hi[d];
+    }
+}
+
 // ================================================================= (2b) scan
 // Exclusive prefix sum of half_cnt[lo..lo+n) into half_off[lo+1..lo+n], continuing from
 // half_off[lo] (0 after a clear, else the previous draw's total).  Three phases over tiles of
@@ -519,15 +588,31 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total_
     return base + inc - v;
 }
 
+// (Thread t of a tile takes entries [16 t, 16 t + 16) as four 16-byte loads when the arrays allow it: a lane that
+// reads its 64 bytes one word at a time makes every load instruction of the wave touch 64 different lines.)
+__device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, uint32_t begin, uint32_t n, uint32_t v[kScanPer]) {
+    if (begin + kScanPer <= n && ((uintptr_t)(cnt + begin) & 15u) == 0) {
+#pragma unroll
+        for (int q = 0; q < kScanPer / 4; ++q) {
+            const uint4 w = reinterpret_cast<const uint4*>(cnt + begin)[q];
+            v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanPer; ++i) v[i] = (begin + i < n) ? cnt[begin + i] : 0u;
+    }
+}
+
 __global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const uint32_t* __restrict__ cnt,
                                                                  uint32_t n,
                                                                  unsigned long long* tile_sum) {
     uint32_t tile = blockIdx.x;
     uint32_t begin = tile * kScanTile + threadIdx.x * kScanPer;
+    uint32_t v[kScanPer];
+    scan_load16(cnt, begin, n, v);
     unsigned long long s = 0;
 #pragma unroll
-    for (int i = 0; i < kScanPer; ++i)
-        if (begin + i < n) s += cnt[begin + i];
+    for (int i = 0; i < kScanPer; ++i) s += v[i];
     // block reduce (u64)
     __shared__ unsigned long long red[kScanThreads / 64];
 #pragma unroll
@@ -584,20 +669,32 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __r
     uint32_t begin = tile * kScanTile + threadIdx.x * kScanPer;
     uint32_t v[kScanPer];
     uint32_t s = 0;
+    scan_load16(cnt, begin, n, v);
 #pragma unroll
-    for (int i = 0; i < kScanPer; ++i) {
-        v[i] = (begin + i < n) ? cnt[begin + i] : 0u;
-        s += v[i];
-    }
+    for (int i = 0; i < kScanPer; ++i) s += v[i];
     uint32_t tot;
     uint32_t ex = block_excl_scan(s, &tot);
     unsigned long long base = tile_base ? tile_base[tile] : (unsigned long long)off[0];
     if (!tile_base && threadIdx.x == 0 && base + tot > 0xFFFFFFFFull) atomicOr(flags, 1u << 4);
     uint32_t run = (uint32_t)base + ex;
+    // off[j + 1] = inclusive sum through j: entries begin + 1 .. begin + 16, i.e. three words, three aligned 16-byte
+    // stores and a last word when the array allows it
+    uint32_t o[kScanPer];
 #pragma unroll
     for (int i = 0; i < kScanPer; ++i) {
         run += v[i];
-        if (begin + i < n) off[begin + i + 1] = run;  // off[j+1] = inclusive sum through j
+        o[i] = run;
+    }
+    if (begin + kScanPer <= n && ((uintptr_t)(off + begin) & 15u) == 0) {
+        off[begin + 1] = o[0]; off[begin + 2] = o[1]; off[begin + 3] = o[2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            reinterpret_cast<uint4*>(off + begin + 4)[q] = make_uint4(o[3 + 4 * q], o[4 + 4 * q], o[5 + 4 * q], o[6 + 4 * q]);
+        off[begin + 16] = o[15];
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanPer; ++i)
+            if (begin + i < n) off[begin + i + 1] = o[i];
     }
 }
 
@@ -699,6 +796,7 @@ struct RasterArgs {
     const uint32_t* half_off;   // exclusive prefix of slots per half (+ total at the end)
     const TriRaster* rast;
     const uint8_t* small_flag;  // k_small: per triangle, 1 = its samples are this kernel's
+    const uint8_t* small_grp;   // k_small: per 32 triangles (tri_seq >> 5), 1 = some triangle of the group is small
     ScanRec* rec;               // records of slots [0, rec_cap); slots beyond are rebuilt on the fly
     uint32_t rec_cap;
     unsigned long long* depth;  // encoded min depth per pixel, row-major
@@ -1171,9 +1269,16 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
     unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
     bool nan_active = false;
     if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
-    for (unsigned long long h64 = (unsigned long long)a.h_lo + blockIdx.x * blockDim.x + threadIdx.x; h64 < a.h_hi;
-         h64 += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t h = (uint32_t)h64;
+    // a wave takes the 64 halves of one GROUP of 32 consecutive triangles at a time; small_grp[g] (a byte k_setup
+    // raises) says whether the group holds a small triangle at all, so a band context walks past the 7/8 of a
+    // 10^7-triangle frame that lie outside its rows at one byte per 32 triangles
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t u_lo = a.h_lo >> 6, u_hi = (uint32_t)(((unsigned long long)a.h_hi + 63ull) >> 6);
+    for (uint32_t u = u_lo + wave_id; u < u_hi; u += n_waves) {
+        if (a.small_grp[u] == 0) continue;  // (the same byte for every lane)
+        const uint32_t h = u * 64u + lane;
+        if (h < a.h_lo || h >= a.h_hi) continue;
         if (a.small_flag[h >> 1] == 0) continue;  // (a byte per triangle: the other triangles' records are not touched)
         if (PASS == 1 && a.use_live && !nan_active && half_live[h] == 0) continue;
         const uint32_t tri = h >> 1, half = h & 1u;
