@@ -587,6 +587,68 @@ def test_texture_destroyed_under_a_recorded_frame(oracle):
         st.close()
 
 
+def test_mid_triangle_path(oracle, monkeypatch):
+    """k_mid (one wave per triangle half: triangles of at most 64 scanlines per half and a bounded sample count, taken by
+    launches of 32 768 triangles or more whose triangles are small on the screen): forced onto every draw here
+    (TR_MID_TRIS=1), with several sample caps so that meshes split between k_mid and the slot sequence.  Whole frames
+    and counters, bands, two draws, a frame extended after a resolve, NaN depths, random triangle soups."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader, ModelRendererState, clear_screen, render_mesh_component
+
+    monkeypatch.setenv("TR_MID_TRIS", "1")
+    for cap in ("4096", "200", "40"):
+        monkeypatch.setenv("TR_MID_SAMPLES", cap)
+        for W, Hh in ((200, 160), (853, 480)):
+            draws = _head_scene(W, Hh, with_eye=True)
+            o = SU.oracle_render(oracle, W, Hh, draws)
+            g = SU.gpu_render(W, Hh, draws, mode=0)
+            info = SU.assert_parity(o, g)
+            assert info["f64_colour_mismatches"] == 0
+            for k in ("samples", "fragments", "scanlines"):
+                assert g["counters"][k] == o["counters"][k], (cap, W, k)
+            top = SU.gpu_render(W, Hh, draws, mode=0, band=(0, 64))
+            assert np.array_equal(top["key"][:, :64], o["key"][:, :64]) and (top["key"][:, 64:] == np.uint64(2**64 - 1)).all()
+    monkeypatch.setenv("TR_MID_SAMPLES", "4096")
+    monkeypatch.setenv("TR_SMALL_DRAW", "1")  # with the small-triangle path as well: three paths in one frame
+    W, Hh = 160, 120
+    draws = _head_scene(W, Hh, with_eye=True)
+    o2 = SU.oracle_render(oracle, W, Hh, draws)
+    st = ModelRendererState(W, Hh, raster_mode=0)
+    try:
+        clear_screen(st)
+        render_mesh_component(st, *draws[0])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        render_mesh_component(st, *draws[1])
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        assert np.array_equal(st.present(), o2["present"])
+        assert np.array_equal(st.winner_keys(), o2["key"])
+        c = st.counters()
+        for k in ("samples", "fragments", "scanlines"):
+            assert c[k] == o2["counters"][k], k
+    finally:
+        st.close()
+    monkeypatch.delenv("TR_SMALL_DRAW")
+    N = H.NONE_INDEX
+    degenerate = H.Object([[-0.5, 0.25, 0.0], [0.5, 0.25, 0.0], [0.0, 0.25, 0.0]],
+                          [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)), [[0, 0, N, 1, 1, N, 2, 2, N]])
+    big = H.Object([[-1, -1, 0.5], [1, -1, 0.5], [-1, 1, 0.5]], np.zeros((0, 3)), np.zeros((0, 3)),
+                   [[0, N, N, 1, N, N, 2, N, N]])
+    d, b = _synthetic_component(degenerate), _synthetic_component(big)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    for order in ((d, b), (b, d)):
+        for W, Hh in ((8, 8), (16, 16), (50, 37)):
+            frame = [(mc, sh) for mc in order]
+            SU.assert_parity(SU.oracle_render(oracle, W, Hh, frame), SU.gpu_render(W, Hh, frame, mode=0))
+    rng = np.random.default_rng(78)
+    for n_tris, W, Hh in ((300, 96, 80), (1500, 64, 64), (60, 24, 16), (400, 200, 120)):
+        draws = _random_scene(rng, n_tris, W, Hh, spread=1.1)
+        o = SU.oracle_render(oracle, W, Hh, draws)
+        g = SU.gpu_render(W, Hh, draws, mode=0)
+        SU.assert_parity(o, g)
+        assert g["counters"]["samples"] == o["counters"]["samples"]
+
+
 def test_deferred_shade_records(oracle, monkeypatch):
     """Draws of 65 536 triangles or more write no TriShade in k_setup; k_build_shade writes it before the shade pass
     for the triangles the winner pass flagged.  Forced onto every draw here (TR_DEFER_SHADE=1 with the unfused

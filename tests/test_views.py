@@ -90,6 +90,7 @@ def test_head_batch_odd_size_and_small_triangle_path(oracle, monkeypatch):
     head = SU.component("head")
     head.transform.set_rotation((0.025, 0.0, 0.0))
     for W, H, small in ((97, 61, False), (200, 160, True), (24, 33, True)):
+        monkeypatch.setenv("TR_MID_TRIS", "0" if (W, H) == (200, 160) else "1")  # (with and without k_mid)
         if small:
             monkeypatch.setenv("TR_SMALL_DRAW", "1")
         st = ModelRendererState(W, H, max_views=4)

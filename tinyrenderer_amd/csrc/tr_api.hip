@@ -105,6 +105,11 @@ struct tr_context {
     uint32_t small_draw_tris = 65536; // draws with at least this many triangles use it (TR_SMALL_DRAW)
     uint32_t small_res = kSmallRes;  // TR_SMALL_RES
     bool small_any = false;          // some draw since tr_clear flagged small triangles
+    bool mid_any = false;            // ... or mid-size ones (k_mid)
+    int mid_path = -1;               // TR_MID_TRIS: 1 every draw may flag mid triangles, 0 none, -1 (default) launches of at
+                                     // least 32 768 triangles that cover fewer than mid_px pixels of the frame on average
+    uint32_t mid_px = 1024;          // TR_MID_PX
+    uint32_t mid_samples = 4096;     // TR_MID_SAMPLES: largest estimated sample count of a half that goes to k_mid
     // row raster (mode 2)
     uint32_t* bin_cnt = nullptr;
     uint32_t* bin_off = nullptr;
@@ -467,6 +472,22 @@ unsigned small_grid(uint32_t n_halves) {
     return want < 1u ? 1u : (want > 8192u ? 8192u : want);
 }
 
+// Workgroups of a k_mid launch (kMidWaves waves each, one wave per half): enough to fill the GPU a few times over.
+unsigned mid_grid(uint32_t n_halves) {
+    const uint32_t want = (n_halves + kMidWaves - 1u) / kMidWaves;
+    return want < 1u ? 1u : (want > 16384u ? 16384u : want);
+}
+
+// Does a launch of n_launch triangles (a draw, or a batch of views of a mesh of n_tris triangles) use k_mid?  One wave
+// per triangle half pays when there are enough halves to fill the GPU several times over and the triangles are
+// small on the screen; a lone 2 492-triangle mesh is 4 984 waves of up to 64 serial rounds each (measured at 800x800:
+// 9.3 k against 16.2 k frames/s through the slot sequence), 32 views of diablo3_pose are 321 000 short ones.
+bool use_mid_path(const tr_context* c, uint64_t n_tris, uint64_t n_launch) {
+    if (c->mode != 0 || n_tris == 0) return false;
+    if (c->mid_path >= 0) return c->mid_path != 0;
+    return n_launch >= 32768u && (uint64_t)c->W * (uint64_t)c->H / n_tris < (uint64_t)c->mid_px;
+}
+
 // passes 0 / 1 over the half range [h_lo, h_hi)
 int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool use_live = false, bool rec_ready = false) {
     RasterArgs ra;
@@ -513,10 +534,17 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
             if (c->precheck) hipLaunchKernelGGL((k_small<0, true>), sg, dim3(256), 0, c->stream, ra, c->half_live);
             else hipLaunchKernelGGL((k_small<0, false>), sg, dim3(256), 0, c->stream, ra, c->half_live);
         }
+        if (c->mid_any) {
+            const dim3 mg(mid_grid(h_hi - h_lo));
+            if (c->precheck) hipLaunchKernelGGL((k_mid<0, true>), mg, dim3(64 * kMidWaves), 0, c->stream, ra, c->half_live);
+            else hipLaunchKernelGGL((k_mid<0, false>), mg, dim3(64 * kMidWaves), 0, c->stream, ra, c->half_live);
+        }
         if (h_hi / 2u > c->counted_upto) c->counted_upto = h_hi / 2u;
     } else {
         if (c->small_any)  // (before k_raster<1>, whose tail zeroes the other half of the per-frame state)
             hipLaunchKernelGGL((k_small<1, false>), dim3(small_grid(h_hi - h_lo)), dim3(256), 0, c->stream, ra, c->half_live);
+        if (c->mid_any)
+            hipLaunchKernelGGL((k_mid<1, false>), dim3(mid_grid(h_hi - h_lo)), dim3(64 * kMidWaves), 0, c->stream, ra, c->half_live);
         // measured on MI355X (4K african_head): the winner pass is faster without the filter
         // (44 vs 52 us), the depth pass with it (71 vs 93 us)
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
@@ -692,6 +720,9 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (const char* e = std::getenv("TR_SMALL_TRIS")) c->small_path = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SMALL_RES")) c->small_res = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SMALL_DRAW")) c->small_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TR_MID_TRIS")) c->mid_path = std::atoi(e);
+    if (const char* e = std::getenv("TR_MID_PX")) c->mid_px = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TR_MID_SAMPLES")) c->mid_samples = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_DEFER_SHADE")) c->defer_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SCAN_RECORDS")) {
@@ -856,6 +887,7 @@ int tr_clear(tr_context* c) {
     if (c->small_any)  // the per-group summary of the small triangles restarts with the frame
         TR_HIP(c, hipMemsetAsync(c->small_grp, 0, c->tri_cap / 32 + 1, c->stream));
     c->small_any = false;
+    c->mid_any = false;
     c->view_tris = 0;
     c->n_views = c->max_views;  // (an empty frame resolves every slice)
     return TR_OK;
@@ -1121,6 +1153,11 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
             sa.small_res = c->small_res;
             c->small_any = true;
         }
+        sa.mid_samples = c->mid_samples;
+        if (use_mid_path(c, (uint64_t)mesh->n_tris, (uint64_t)mesh->n_tris)) {
+            sa.mode |= 16;  // triangles of up to 64 scanlines per half and a few hundred samples: one wave per half (k_mid)
+            c->mid_any = true;
+        }
         sa.need_shade = c->need_shade;
         if (defer) sa.mode |= 8;  // no TriShade now: k_build_shade writes it for the triangles the winner pass flags
         sa.per_corner = defer ? 1 : 0;
@@ -1247,6 +1284,11 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
             sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots
             sa.small_res = c->small_res;
             c->small_any = true;
+        }
+        sa.mid_samples = c->mid_samples;
+        if (use_mid_path(c, (uint64_t)mesh->n_tris, total)) {
+            sa.mode |= 16;  // triangles of up to 64 scanlines per half and a few hundred samples: one wave per half (k_mid)
+            c->mid_any = true;
         }
         sa.draw_table = c->draw_table;
         sa.half_off = c->half_off;

@@ -57,8 +57,9 @@ struct SetupArgs {
     uint32_t* tile_cnt;    // triangles per tile (tile raster only)
     int tiles_x, tiles_y;
     int y_lo, y_hi;        // band of pixel rows owned by this context
-    int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small),
+    int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small), bit4: flag mid ones (k_mid),
                            // bit3: no TriShade now (k_build_shade writes it for the triangles the winner pass flags)
+    uint32_t mid_samples;  // mode bit 4: a triangle of at most 64 scanlines per half and about this many samples per half goes to k_mid
     uint32_t small_res;    // a triangle is small if neither half has more than small_res + 1 scanlines
     uint8_t* small_flag;   // per triangle: 1 = flagged kTriSmall (what k_small reads)
     uint8_t* small_grp;    // per 32 triangles: raised if one of them is small (k_small skips the other groups)
@@ -338,7 +339,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         cull = cull && out;
     }
     TriRaster R;
-    bool small = false;
+    bool small = false, mid = false;
     R.res[0] = R.res[1] = 0;
     R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0; R.slot_shift = 0;
     R.pad[0] = R.pad[1] = 0;
@@ -470,6 +471,17 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
             R.flags |= kTriSmall;
             small = true;
         }
+        // A triangle of at most 64 scanlines per half and a few hundred samples is one WAVE per half in k_mid: its
+        // scanlines are built in registers, its samples spread over the lanes; no slots, no records, no searches in
+        // memory.  (mode bit 4: the draw uses that path -- meshes whose triangles cover some hundreds of pixels.)
+        if ((a.mode & 16) && !small && res0 && res0 <= 63u && res1 <= 63u && !(R.flags & kTriNonFinite)) {
+            const double ext = fmax(fabs(R.sp[0] - R.s1[0]), fabs(R.sp[1] - R.s1[1]));  // the longest scanline
+            const double est = (double)((res0 > res1 ? res0 : res1) + 1u) * (ext * 0.5 + 2.0);
+            if (est <= (double)a.mid_samples) {  // (NaN: no)
+                mid = true;
+                small = true;  // (owns no slots either)
+            }
+        }
         a.rast[seq] = R;
         if ((a.mode & 2) && res0) {
             if (R.flags & kTriNonFinite) {
@@ -484,11 +496,11 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         }
         }  // !out_of_band
     }
-    if (a.small_flag) a.small_flag[seq] = small ? 1 : 0;  // (every draw writes it: k_small may sweep draws that do not use the path)
-    if (small) a.small_grp[seq >> 5] = 1;  // (zeroed by tr_clear; lanes of a group store the same byte)
-    // deferred shade record: a triangle with slots always gets one (k_raster keeps no per-triangle state); one of a
-    // few pixels (k_small, the bulk of a high-polygon mesh) only if the winner pass flags it
-    if (a.mode & 8) a.need_shade[seq] = (res0 && !small) ? 1 : 0;
+    if (a.small_flag) a.small_flag[seq] = mid ? 2 : (small ? 1 : 0);  // (every draw writes it: k_small / k_mid may sweep draws that do not use them)
+    if (small && !mid) a.small_grp[seq >> 5] = 1;  // (zeroed by tr_clear; lanes of a group store the same byte)
+    // deferred shade record: a triangle with slots (or of k_mid) always gets one (those kernels keep no per-triangle
+    // state); one of a few pixels (k_small, the bulk of a high-polygon mesh) only if the winner pass flags it
+    if (a.mode & 8) a.need_shade[seq] = (res0 && (!small || mid)) ? 1 : 0;
     if (a.mode & 1) {  // slots per half
         cnt0 = res0 && !small ? (res0 + 1u) << R.slot_shift : 0u;
         cnt1 = res1 && !small ? (res1 + 1u) << R.slot_shift : 0u;
@@ -1279,7 +1291,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
         if (a.small_grp[u] == 0) continue;  // (the same byte for every lane)
         const uint32_t h = u * 64u + lane;
         if (h < a.h_lo || h >= a.h_hi) continue;
-        if (a.small_flag[h >> 1] == 0) continue;  // (a byte per triangle: the other triangles' records are not touched)
+        if (a.small_flag[h >> 1] != 1) continue;  // (a byte per triangle: the other triangles' records are not touched)
         if (PASS == 1 && a.use_live && !nan_active && half_live[h] == 0) continue;
         const uint32_t tri = h >> 1, half = h & 1u;
         const TriRaster& t = a.rast[tri];
@@ -1389,6 +1401,143 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
 template __global__ void k_small<0, true>(RasterArgs, uint8_t*);
 template __global__ void k_small<0, false>(RasterArgs, uint8_t*);
 template __global__ void k_small<1, false>(RasterArgs, uint8_t*);
+
+// ---------------------------------------------------------------- mid-size triangles
+// The same two passes for triangles k_setup flagged for this path (small_flag == 2: at most 64 scanlines per half,
+// a few hundred samples; they own no slots): one WAVE per triangle half.  Lane i builds scanline i
+// (make_scanline: mod.rs:376-379, segment_3d/mod.rs:26-48) and keeps it in the wave's corner of LDS, a wave scan of
+// the scanlines' sample counts follows, and then the lanes own SAMPLES of the half in the reference's order --
+// consecutive lanes are consecutive samples of a scanline, i.e. neighbouring pixels of a row.  Against the slot
+// sequence this needs no prefix over the frame, no records in memory, no search through half_off and no barrier:
+// a mesh whose triangles cover tens to hundreds of pixels (BASELINE.json configs[4]: diablo3_pose at 1080p, 9 samples
+// to a scanline) fills a 64-slot chunk of the global raster with a few hundred samples and spends its time in the
+// chunk's fixed costs.
+constexpr int kMidWaves = 4;
+template <int PASS, bool PRECHECK>
+__global__ __launch_bounds__(64 * kMidWaves) void k_mid(RasterArgs a, uint8_t* half_live) {
+    __shared__ double sRec[kMidWaves][64][7];      // A, B - A, 1 / hres of the half's scanlines
+    __shared__ uint32_t sPre[kMidWaves][65];       // exclusive prefix of their sample counts
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
+    bool nan_active = false;
+    if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
+    auto lds_sync = [] {  // (one wave: its LDS operations execute in order; this only pins the compiler)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (unsigned long long h64 = (unsigned long long)a.h_lo + wave_id; h64 < a.h_hi; h64 += n_waves) {
+        const uint32_t h = (uint32_t)h64;  // (the same for every lane)
+        if (a.small_flag[h >> 1] != 2) continue;
+        if (PASS == 1 && a.use_live && !nan_active && half_live[h] == 0) continue;
+        const uint32_t tri = h >> 1, half = h & 1u;
+        const TriRaster& t = a.rast[tri];
+        const uint32_t res = t.res[half];  // (2 .. 63)
+        const bool counted = h >= a.count_h;
+        const uint32_t vw = a.view_tris ? tri / a.view_tris : 0u;
+        const uint32_t pix_base = vw * a.view_pix, blk_base = vw * a.view_blk;
+        lds_sync();  // the previous half's readers are done with the wave's corner of LDS
+        uint32_t cnt = 0;
+        if (lane <= res) {
+            const Scanline sl = make_scanline(t, half, lane, 1.0 / (double)res);
+            double* r = sRec[w][lane];
+            r[0] = sl.ax; r[1] = sl.ay; r[2] = sl.az; r[3] = sl.dx; r[4] = sl.dy; r[5] = sl.dz;
+            r[6] = 1.0 / (double)sl.hres;
+            cnt = sl.hres + 1u;  // (hres <= 65: the half's extent is at most 63 pixels)
+        }
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += up;
+        }
+        sPre[w][lane + 1] = inc;
+        if (lane == 0) sPre[w][0] = 0;
+        lds_sync();
+        const uint32_t total = sPre[w][64];
+        if (PASS == 0 && counted) {
+            cnt_scan += lane == 0 ? res + 1u : 0u;
+            cnt_samples += lane == 0 ? total : 0u;
+        }
+        bool live = false;
+        for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
+            const uint32_t k = k0 + lane;
+            if (k >= total) continue;  // (only in the last round)
+            uint32_t sidx = 0;  // the last scanline whose first sample is <= k
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1)
+                if (sPre[w][sidx + step] <= k) sidx += step;
+            const uint32_t j = k - sPre[w][sidx];
+            const double* r = sRec[w][sidx];
+            const double sp = (double)j * r[6];
+            const double x = r[0] + sp * r[3];
+            const double y = r[1] + sp * r[4];
+            const double z = r[2] + sp * r[5];
+            const int ix = pixel_coord(x, a.W);
+            const int iy = pixel_coord(y, a.H);
+            const bool inb = ix >= 0 && iy >= a.y_lo && iy < a.y_hi;
+            if (PASS == 0 && counted) cnt_inb += inb ? 1 : 0;
+            if (!inb) continue;
+            const double dist = -z;
+            const uint32_t pix = pix_base + (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+            const unsigned long long key = ((unsigned long long)tri << kKeyTriShift) | ((unsigned long long)half << kKeyHalfShift) |
+                                           ((unsigned long long)sidx << kKeyIShift) | (unsigned long long)j;
+            if (dist != dist) {  // NaN depth: the side table, as in k_raster
+                if (PASS == 0) {
+                    live = true;
+                    bool placed = false;
+                    for (uint32_t s = 0; s < kNanSlots && !placed; ++s) {
+                        uint32_t old = atomicCAS(&a.nan->pix[s], kNanEmpty, pix);
+                        placed = old == kNanEmpty || old == pix;
+                    }
+                    if (!placed) atomicOr(a.flags, 1u << 5);
+                } else if (nan_active) {
+                    for (uint32_t s = 0; s < kNanSlots; ++s)
+                        if (a.nan->pix[s] == pix) atomicMin((unsigned long long*)&a.nan->first_nan[s], key);
+                }
+                continue;
+            }
+            const unsigned long long enc = encode_depth(dist);
+            if (PASS == 0) {
+                if (dist == -__builtin_huge_val()) atomicOr(a.flags, 1u << 3);
+                const unsigned long long cur = PRECHECK ? a.depth[pix] : ~0ull;
+                if (!PRECHECK || enc <= cur) live = true;
+                if (!PRECHECK || enc < cur) atomicMin(&a.depth[pix], enc);
+            } else {
+                if (nan_active) {
+                    for (uint32_t s = 0; s < kNanSlots; ++s)
+                        if (a.nan->pix[s] == pix) atomicMin((unsigned long long*)&a.nan->first_any[s], key);
+                }
+                if (a.depth[pix] == enc) {
+                    atomicMin(&a.wkey[pix], key);
+                    a.blk_touched[2u * (blk_base + (uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW))] = 1;
+                }
+            }
+        }
+        if (PASS == 0) {
+            const bool any_live = __ballot(live) != 0ull;
+            if (lane == 0) half_live[h] = any_live ? 1 : 0;
+        }
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            cnt_samples += __shfl_down(cnt_samples, d, 64);
+            cnt_inb += __shfl_down(cnt_inb, d, 64);
+            cnt_scan += __shfl_down(cnt_scan, d, 64);
+        }
+        if (lane == 0 && (cnt_samples | cnt_scan)) {
+            unsigned long long* slot = a.counters + (size_t)((blockIdx.x * kMidWaves + w) % kCounterSlots) * 8;
+            atomicAdd(&slot[0], cnt_samples);
+            atomicAdd(&slot[1], cnt_inb);
+            atomicAdd(&slot[2], cnt_scan);
+        }
+    }
+}
+template __global__ void k_mid<0, true>(RasterArgs, uint8_t*);
+template __global__ void k_mid<0, false>(RasterArgs, uint8_t*);
+template __global__ void k_mid<1, false>(RasterArgs, uint8_t*);
 
 template __global__ void k_setup<false, false>(SetupArgs);
 template __global__ void k_setup<true, false>(SetupArgs);
