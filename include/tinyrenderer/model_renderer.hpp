@@ -87,8 +87,11 @@ struct BuiltinShader {
 // back in the reference's layout (Array3<f64> of shape (W, H, C), x the slow axis).
 class ModelRendererState {
   public:
-    ModelRendererState(size_t frame_width, size_t frame_height, int device = 0) : w_(frame_width), h_(frame_height) {
-        const int rc = tr_create(device, (int)frame_width, (int)frame_height, &ctx_);
+    // max_views > 1: a state whose planes hold that many W x H slices, for render_views (tr_create_views)
+    ModelRendererState(size_t frame_width, size_t frame_height, int device = 0, int max_views = 1)
+        : w_(frame_width), h_(frame_height), max_views_(max_views) {
+        const int rc = max_views > 1 ? tr_create_views(device, (int)frame_width, (int)frame_height, max_views, &ctx_)
+                                     : tr_create(device, (int)frame_width, (int)frame_height, &ctx_);
         if (rc != TR_OK)
             throw RendererError("ModelRendererState::new: tr_create failed (" + std::to_string(rc) +
                                 "); a gfx950 GPU is required, there is no CPU fallback");
@@ -104,7 +107,10 @@ class ModelRendererState {
 
     size_t frame_width() const { return w_; }
     size_t frame_height() const { return h_; }
+    int max_views() const { return max_views_; }
     tr_context* context() { return ctx_; }
+    // the slice of a render_views batch that z_buffer / frame_buffer / present refer to
+    void select_view(int view) { check(tr_select_view(ctx_, view), "tr_select_view"); }
 
     // state.z_buffer.nd_img: (W, H, 1) f64, -inf where nothing was drawn
     std::vector<double> z_buffer() {
@@ -159,6 +165,7 @@ class ModelRendererState {
   private:
     tr_context* ctx_ = nullptr;
     size_t w_, h_;
+    int max_views_ = 1;
     std::map<const Object*, tr_mesh*> meshes_;
     std::map<const RgbaImage*, tr_texture*> textures_;
 };
@@ -193,11 +200,21 @@ struct ShadeExt {
     double shadow_bias = 0.0, shadow_dim = 0.3;
 };
 
-// render_mesh_component(state, &mesh, VS, FS) (mod.rs:225-230) with the closure pair replaced by
-// `shader`; takes the MeshComponent so the textures the closures capture (main.rs:140-141) come along.
-// `ext` (no counterpart in the reference) selects an extension shader.
-inline void render_mesh_component(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader,
-                                  const ShadeExt* ext = nullptr) {
+inline tr_draw_params make_draw_params(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader);
+
+// One iteration of the reference's loop per shader -- clear_screen + render_mesh_component(state, &mesh, VS, FS)
+// (src/main.rs:57-116,272-273) -- for ONE mesh under shaders.size() cameras, as a single batch (tr_render_views):
+// view v lands in slice v of a state made with max_views; select_view(v) picks the slice the buffers read.
+inline void render_views(ModelRendererState& state, const MeshComponent& mesh_component, const std::vector<BuiltinShader>& shaders,
+                         uint32_t out_mask = TR_OUT_RGBA8) {
+    std::vector<tr_draw_params> params;
+    params.reserve(shaders.size());
+    for (const BuiltinShader& sh : shaders) params.push_back(make_draw_params(state, mesh_component, sh));
+    state.check(tr_render_views(state.context(), state.mesh_handle(mesh_component.mesh), params.data(), (int)params.size(), out_mask),
+                "tr_render_views");
+}
+
+inline tr_draw_params make_draw_params(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader) {
     tr_draw_params p{};
     const Matrix4 pmv = shader.perspective_matrix * shader.model_view_matrix;  // main.rs:152-153
     for (int i = 0; i < 16; ++i) {
@@ -211,6 +228,15 @@ inline void render_mesh_component(ModelRendererState& state, const MeshComponent
     p.use_normal_map = shader.use_normal_map ? 1 : 0;
     p.diffuse = state.texture_handle(mesh_component.texture);
     p.normal_map = state.texture_handle(mesh_component.normal_map);
+    return p;
+}
+
+// render_mesh_component(state, &mesh, VS, FS) (mod.rs:225-230) with the closure pair replaced by
+// `shader`; takes the MeshComponent so the textures the closures capture (main.rs:140-141) come along.
+// `ext` (no counterpart in the reference) selects an extension shader.
+inline void render_mesh_component(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader,
+                                  const ShadeExt* ext = nullptr) {
+    const tr_draw_params p = make_draw_params(state, mesh_component, shader);
     if (!ext) {
         state.check(tr_draw(state.context(), state.mesh_handle(mesh_component.mesh), &p), "tr_draw");
         return;
