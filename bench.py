@@ -365,7 +365,9 @@ def main():
     shade_bytes = W * H * 12 + vis_tris * 320 + tex_bytes
     traffic = None
     try:  # HBM bytes per k_shade launch from the committed PMC passes (same workload only)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_pmc_4k.json")))
+        import glob
+
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_pmc_4k.json")))[-1]))  # the latest round's
         if pmc["workload"]["W"] == W and pmc["workload"]["H"] == H:
             traffic = pmc["k_shade_hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):

@@ -312,6 +312,10 @@ constexpr int kScanlineBlocks = 2048;
 constexpr int kRowGrid = 256 * 15;  // waves: 15 per CU fit the LDS (10.3 KB each)
 constexpr uint32_t kChunkLiveCap = 1u << 20;  // 64 M slots per frame get dead-chunk skipping
 
+// (a wave per block of 1 << shift halves: single halves while there are fewer than a million, so that a batch of
+// views fills the GPU; blocks of 16 for the meshes of millions of triangles, few of which are of this path)
+uint32_t mid_shift_for(uint32_t n_halves) { return n_halves >= (4u << 20) ? 4u : (n_halves >= (1u << 20) ? 2u : 0u); }
+
 void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_hi) {
     ra.half_off = c->half_off;
     ra.rast = c->rast;
@@ -341,6 +345,7 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.clean_words = 0;
     ra.clean_nan = nullptr;
     ra.need_shade = c->deferred.empty() ? nullptr : c->need_shade;
+    ra.mid_shift = mid_shift_for(h_hi - h_lo);
     ra.view_tris = c->view_tris;
     ra.view_pix = (uint32_t)((size_t)c->W * c->H);
     ra.view_blk = c->blk_per_view;
@@ -474,7 +479,7 @@ unsigned small_grid(uint32_t n_halves) {
 
 // Workgroups of a k_mid launch (kMidWaves waves each, one wave per half): enough to fill the GPU a few times over.
 unsigned mid_grid(uint32_t n_halves) {
-    const uint32_t want = (n_halves + kMidWaves - 1u) / kMidWaves;
+    const uint32_t want = ((n_halves >> mid_shift_for(n_halves)) + kMidWaves) / kMidWaves;
     return want < 1u ? 1u : (want > 16384u ? 16384u : want);
 }
 
@@ -485,7 +490,9 @@ unsigned mid_grid(uint32_t n_halves) {
 bool use_mid_path(const tr_context* c, uint64_t n_tris, uint64_t n_launch) {
     if (c->mode != 0 || n_tris == 0) return false;
     if (c->mid_path >= 0) return c->mid_path != 0;
-    return n_launch >= 32768u && (uint64_t)c->W * (uint64_t)c->H / n_tris < (uint64_t)c->mid_px;
+    // (below 16 pixels per triangle on average nearly every triangle is one of k_small's)
+    const uint64_t px_per_tri = (uint64_t)c->W * (uint64_t)c->H / n_tris;
+    return n_launch >= 32768u && px_per_tri >= 16u && px_per_tri < (uint64_t)c->mid_px;
 }
 
 // passes 0 / 1 over the half range [h_lo, h_hi)

@@ -835,6 +835,7 @@ struct RasterArgs {
     // batched views (tr_render_views): triangle t belongs to view t / view_tris, whose planes start view_pix
     // pixels and whose shade blocks start view_blk blocks after the previous view's; 0 = one view
     uint32_t view_tris, view_pix, view_blk;
+    uint32_t mid_shift;         // k_mid: log2 of the halves a wave looks up at once (0 .. 6)
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
     unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
                                 // ticks, samples | block << 32)
@@ -1427,10 +1428,23 @@ __global__ __launch_bounds__(64 * kMidWaves) void k_mid(RasterArgs a, uint8_t* h
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    for (unsigned long long h64 = (unsigned long long)a.h_lo + wave_id; h64 < a.h_hi; h64 += n_waves) {
-        const uint32_t h = (uint32_t)h64;  // (the same for every lane)
-        if (a.small_flag[h >> 1] != 2) continue;
-        if (PASS == 1 && a.use_live && !nan_active && half_live[h] == 0) continue;
+    // A wave takes BLOCKS of 1 << mid_shift consecutive halves: that many lanes look their flags up at once and the
+    // wave then visits the halves that are its business one after the other.  (One flag load per half and wave cost a
+    // 10^7-triangle frame, few of whose triangles are of this path, 1.9 ms of dependent loads; large blocks leave an
+    // orbit batch of 10^5 halves with too few wave-sized pieces of work to fill the GPU: the host sizes them.)
+    const uint32_t bs = a.mid_shift, bn = 1u << bs;
+    const uint32_t b_lo = a.h_lo >> bs, b_hi = (uint32_t)(((unsigned long long)a.h_hi + bn - 1ull) >> bs);
+    for (uint32_t blk = b_lo + wave_id; blk < b_hi; blk += n_waves) {
+      bool mine = false;
+      if (lane < bn) {
+          const uint32_t hl = blk * bn + lane;
+          mine = hl >= a.h_lo && hl < a.h_hi && a.small_flag[hl >> 1] == 2;
+          if (mine && PASS == 1 && a.use_live && !nan_active) mine = half_live[hl] != 0;
+      }
+      unsigned long long todo = __ballot(mine);
+      while (todo) {
+        const uint32_t h = blk * bn + (uint32_t)__builtin_ctzll(todo);  // (the same for every lane)
+        todo &= todo - 1ull;
         const uint32_t tri = h >> 1, half = h & 1u;
         const TriRaster& t = a.rast[tri];
         const uint32_t res = t.res[half];  // (2 .. 63)
@@ -1519,6 +1533,7 @@ __global__ __launch_bounds__(64 * kMidWaves) void k_mid(RasterArgs a, uint8_t* h
             const bool any_live = __ballot(live) != 0ull;
             if (lane == 0) half_live[h] = any_live ? 1 : 0;
         }
+      }  // halves of the block
     }
     if (PASS == 0) {
 #pragma unroll

@@ -7,7 +7,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof
 rm -rf "$OUT" && mkdir -p "$OUT"
-BENCH="python3 bench.py --contexts 1 --steps 40 --warmup 5 --no-cpu-baseline --profile-frames 0"
+BENCH="python3 bench.py --contexts 1 --steps 2 --warmup 1 --frames-per-step 20 --no-cpu-baseline --no-secondary --profile-frames 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o ks -- $BENCH > "$OUT/stats.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o pmc -- $BENCH > "$OUT/fetch.log" 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- $BENCH > "$OUT/write.log" 2>&1
@@ -15,10 +15,12 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CY
 timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/tcc" -o pmc -- $BENCH > "$OUT/tcc.log" 2>&1
 # the headline command itself (four contexts in flight): kernel durations there include the time a kernel
 # shares the GPU with those of three other frames; tools/overlap_report.py summarises the overlap
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o ks -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --profile-frames 0 > "$OUT/stats4.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -o ks -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --profile-frames 0 > "$OUT/stats4.log" 2>&1
 python3 tools/overlap_report.py "$(ls $OUT/stats4/*/ks_kernel_trace.csv $OUT/stats4/ks_kernel_trace.csv 2>/dev/null | head -1)" > "$OUT/overlap4.txt" 2>&1 || true
 # the other configurations of BASELINE.json rehearsed on one GPU: kernel summaries only
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/orbit" -o ks -- python3 tools/orbit_bench.py 512 1920 1080 1 > "$OUT/orbit.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/orbit_batch" -o ks -- python3 tools/orbit_batch_bench.py 512 32 1 > "$OUT/orbit_batch.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/band" -o ks -- python3 tools/band_one.py 3 8 > "$OUT/band.log" 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/shadow" -o ks -- python3 tests/manual/diablo_shadow.py 1024 1024 1024 > "$OUT/shadow.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bigmesh" -o ks -- python3 tests/manual/big_mesh_check.py 6 7680 4320 0 0 > "$OUT/bigmesh.log" 2>&1
 # the headline command without the profiler, for the committed bench line

@@ -9,7 +9,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = "gpurun_out/prof"
 os.makedirs("profiles", exist_ok=True)
 
@@ -32,12 +32,13 @@ if stats4:
     shutil.copy(stats4[0], f"profiles/{tag}_kernel_stats_4k_4ctx.csv")
 if os.path.exists(os.path.join(src, "overlap4.txt")):
     shutil.copy(os.path.join(src, "overlap4.txt"), f"profiles/{tag}_overlap_4k_4ctx.txt")
-for sub, name in (("orbit", "orbit_1080p_1ctx"), ("shadow", "diablo_shadow_1024"), ("bigmesh", "bigmesh_10M_8k")):
+for sub, name in (("orbit", "orbit_1080p_1ctx"), ("orbit_batch", "orbit_1080p_batch32"), ("band", "band3of8_10M_8k"),
+                  ("shadow", "diablo_shadow_1024"), ("bigmesh", "bigmesh_10M_8k")):
     f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if f:
         shutil.copy(f[0], f"profiles/{tag}_kernel_stats_{name}.csv")
 pmc = {"source": "tools/collect_profiles.sh: rocprofv3 --pmc, one counter set per run, python3 bench.py --contexts 1 "
-                 "--steps 40 --warmup 5, african_head 3840x2160, global raster, RGBA8-only resolve",
+                 "--steps 2 --warmup 1 --frames-per-step 20, african_head 3840x2160, global raster, RGBA8-only resolve",
        "units": "FETCH_SIZE / WRITE_SIZE in KB per launch as rocprofv3 reports them, averaged over launches",
        "gfx950_correction": "FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section): doubled; WRITE_SIZE as is",
        "workload": {"W": 3840, "H": 2160, "scene": "african_head"}, "kernels": {}}
