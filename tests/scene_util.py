@@ -54,7 +54,7 @@ def oracle_render(oracle, W, H, draws):
 
 
 def gpu_render(W, H, draws, device=0, mode=None, band=None):
-    """mode: None (library default = tile raster), _ffi.TR_RASTER_TILE or _ffi.TR_RASTER_GLOBAL."""
+    """mode: None (library default = global raster), _ffi.TR_RASTER_GLOBAL, _ffi.TR_RASTER_TILE or _ffi.TR_RASTER_ROWS."""
     st = ModelRendererState(W, H, device=device, raster_mode=mode)
     try:
         clear_screen(st)
