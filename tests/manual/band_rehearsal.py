@@ -4,7 +4,7 @@ frame cut into the tile-row bands that 1/2/4/8 GPUs would own (sharding.band_row
 Every band is rendered and timed by itself on this GPU; the slowest band of a cut is what a node of
 that many GPUs would take per frame before the RGBA8 gather.  The bands are stitched and compared
 with the whole frame (winner keys), and the whole frame with the oracle if asked.
-    python tests/manual/band_rehearsal.py [levels=6] [W=7680] [H=4320] [oracle=0]"""
+    python tests/manual/band_rehearsal.py [levels=6] [W=7680] [H=4320] [oracle=0] [rounds=8]"""
 import os
 import sys
 import time
@@ -21,6 +21,7 @@ def main():
     W = int(sys.argv[2]) if len(sys.argv) > 2 else 7680
     H = int(sys.argv[3]) if len(sys.argv) > 3 else 4320
     with_oracle = (int(sys.argv[4]) if len(sys.argv) > 4 else 0) != 0
+    rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 8
     import scene_util as SU
     from tinyrenderer_amd import _ffi, scenes, sharding
     from tinyrenderer_amd.model_renderer import MeshComponent, ModelRendererState, clear_screen, render_mesh_component
@@ -51,11 +52,11 @@ def main():
     print(f"whole frame: {t_full:.2f} ms", flush=True)
     # Rebalancing as a node would do it: every rank knows how long its band took last frame; the cost
     # per tile row is taken constant inside a band, and the next frame's cuts equalise it
-    # (sharding.balanced_bands).  Three rounds starting from equal rows.
+    # (sharding.balanced_bands), damped; `rounds` frames starting from equal rows.
     n_rows = (H + sharding.TILE - 1) // sharding.TILE
     for world in (2, 4, 8):
         bands = [sharding.band_rows(H, r, world) for r in range(world)]
-        for it in range(4):
+        for it in range(rounds):
             times, key = [], np.full_like(key_full, np.uint64(0xFFFFFFFFFFFFFFFF))
             for y_lo, y_hi in bands:
                 times.append(run((y_lo, y_hi)))

@@ -94,6 +94,8 @@ struct tr_context {
     uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
     uint8_t* small_grp = nullptr;    // per 32 triangles: some triangle of the group is small (tri_cap / 32 + 1 bytes)
+    uint8_t* cluster_cull = nullptr; // band contexts: a byte per 64-triangle cluster of the frame's big draws (k_cull_clusters)
+    size_t cull_cap = 0, cull_used = 0;
     uint8_t* need_shade = nullptr;   // deferred shade records: per triangle, flagged by the winner pass (tri_cap bytes)
     uint32_t defer_tris = 65536;     // draws with at least this many triangles defer their shade records (TR_DEFER_SHADE)
     struct Deferred { const tr_mesh* mesh; SetupArgs sa; };
@@ -383,18 +385,20 @@ Mat4 viewport_matrix(int W, int H) {
 }
 
 // The scanline prefix of halves [lo, lo + n_halves), continuing from the previous draw's total.
-int launch_scan(tr_context* c, uint32_t lo, uint32_t n_halves) {
+constexpr unsigned kBandSetupBlocks = 8192;  // grid of k_setup / k_build_shade in a band context (256 threads each)
+int launch_scan(tr_context* c, uint32_t lo, uint32_t n_halves, const uint8_t* cull = nullptr) {
+    const uint32_t n_clusters = (n_halves / 2u + 63u) / 64u;  // (of the draw whose halves these are, when `cull` is given)
     uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
     if (tiles <= 8) {
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
                            c->half_off + lo, c->flags);
     } else {
         hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo,
-                           n_halves, c->tile_sum);
+                           n_halves, c->tile_sum, cull, n_clusters);
         hipLaunchKernelGGL(k_scan_tile_bases, dim3(1), dim3(kScanThreads), 0, c->stream, c->tile_sum, tiles,
                            c->half_off + lo, c->flags);
         hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanThreads), 0, c->stream, c->half_cnt + lo, n_halves,
-                           c->half_off + lo, (const unsigned long long*)c->tile_sum, c->flags);
+                           c->half_off + lo, (const unsigned long long*)c->tile_sum, c->flags, cull, n_clusters);
     }
     TR_HIP(c, hipGetLastError());
     return TR_OK;
@@ -828,7 +832,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->small_grp); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->small_grp); (void)hipFree(c->cluster_cull); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);
@@ -890,6 +894,7 @@ int tr_clear(tr_context* c) {
     c->frame_textures.clear();
     c->frame_lost_texture = false;
     c->deferred.clear();
+    c->cull_used = 0;
     c->frame_lost_mesh = false;
     if (c->small_any)  // the per-group summary of the small triangles restarts with the frame
         TR_HIP(c, hipMemsetAsync(c->small_grp, 0, c->tri_cap / 32 + 1, c->stream));
@@ -1169,6 +1174,26 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         if (defer) sa.mode |= 8;  // no TriShade now: k_build_shade writes it for the triangles the winner pass flags
         sa.per_corner = defer ? 1 : 0;
         sa.bounds = mesh->bounds;
+        sa.cull = nullptr;
+        if (defer && mesh->bounds && (c->y_lo > 0 || c->y_hi < c->H)) {
+            // a band context: whole clusters of the mesh that miss its rows are dropped before anything of theirs is read
+            const size_t n_clusters = ((size_t)mesh->n_tris + 63) / 64;
+            if (c->cull_used + n_clusters > c->cull_cap) {
+                // (grown between frames only: an earlier draw of this frame may still hold a pointer into it)
+                if (c->cull_used == 0) {
+                    (void)hipFree(c->cluster_cull);
+                    c->cluster_cull = nullptr; c->cull_cap = 0;
+                    size_t cap = 4096;
+                    while (cap < n_clusters) cap *= 2;
+                    TR_HIP(c, hipMalloc(&c->cluster_cull, cap));
+                    c->cull_cap = cap;
+                }
+            }
+            if (c->cull_used + n_clusters <= c->cull_cap) {
+                sa.cull = c->cluster_cull + c->cull_used;
+                c->cull_used += n_clusters;
+            }
+        }
         DrawDev& d = sa.params;
         fill_draw_dev(d, p);
         sa.draw_table = c->draw_table;
@@ -1188,11 +1213,21 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
             const int threads = (st == 64 || st == 256) ? st : 128;
             hipLaunchKernelGGL((k_setup<true>), dim3((unsigned)((mesh->n_tris + threads - 1) / threads)), dim3(threads), 0, c->stream, sa);
         }
-        else hipLaunchKernelGGL((k_setup<false>), dim3((unsigned)((mesh->n_tris + 255) / 256)), dim3(256), 0, c->stream, sa);
+        else {
+            unsigned blocks = (unsigned)((mesh->n_tris + 255) / 256);
+            if (sa.cull) {
+                const uint32_t n_clusters = (uint32_t)(((size_t)mesh->n_tris + 63) / 64);
+                hipLaunchKernelGGL(k_cull_clusters, dim3((n_clusters * 8u + 255u) / 256u), dim3(256), 0, c->stream, sa, n_clusters);
+                TR_HIP(c, hipGetLastError());
+                if (blocks > kBandSetupBlocks) blocks = kBandSetupBlocks;  // a fixed grid strides over the clusters kept
+            }
+            if (sa.cull) hipLaunchKernelGGL((k_setup<false, false, true>), dim3(blocks), dim3(256), 0, c->stream, sa);
+            else hipLaunchKernelGGL((k_setup<false>), dim3(blocks), dim3(256), 0, c->stream, sa);
+        }
         TR_HIP(c, hipGetLastError());
         if (c->mode != 1 && !fused) {
             // prefix of scanline counts, continuing from the previous draw's total
-            rc = launch_scan(c, 2u * tri_base, n_halves);
+            rc = launch_scan(c, 2u * tri_base, n_halves, sa.cull);
             if (rc != TR_OK) return rc;
         }
     }
@@ -1456,7 +1491,10 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             ProfScope ps(c, ST_SETUP);
             SetupArgs ba = d.sa;
             ba.rast = c->rast; ba.shade = c->shade;  // (the arrays may have grown since the draw)
-            hipLaunchKernelGGL(k_build_shade, dim3((unsigned)((ba.n_tris + 255) / 256)), dim3(256), 0, c->stream, ba, c->need_shade);
+            unsigned blocks = (unsigned)((ba.n_tris + 255) / 256);
+            if (ba.cull && blocks > kBandSetupBlocks) blocks = kBandSetupBlocks;
+            if (ba.cull) hipLaunchKernelGGL(k_build_shade<true>, dim3(blocks), dim3(256), 0, c->stream, ba, c->need_shade);
+            else hipLaunchKernelGGL(k_build_shade<false>, dim3(blocks), dim3(256), 0, c->stream, ba, c->need_shade);
             TR_HIP(c, hipGetLastError());
         }
     }

@@ -141,8 +141,9 @@ __device__ __forceinline__ void normalize4_w0(double& x, double& y, double& z) {
 // Monotone u64 image of a non-NaN double, with -0 folded onto +0 (the reference's
 // `current_z > dist` test cannot tell the zeros apart).
 __device__ __forceinline__ uint64_t encode_depth(double d) {
-    uint64_t b = (uint64_t)__double_as_longlong(d + 0.0);
-    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+    const uint64_t b = (uint64_t)__double_as_longlong(d + 0.0);
+    // negative: every bit flipped, else the sign bit set (sign mask by an arithmetic shift: 4 instructions, no compare)
+    return b ^ ((uint64_t)((int64_t)b >> 63) | 0x8000000000000000ull);
 }
 
 // Rust `v.ceil() as i64` followed by `.max(2)` for v >= 0 or NaN; values above `limit`
@@ -165,6 +166,17 @@ __device__ __forceinline__ int pixel_coord(double v, int n) {
     const double x = v + copysign(0.49999999999999994, v);
     if (x > -1.0 && x < (double)n) return (int)x;  // trunc(x) in [0, n-1]
     return x != x ? 0 : -1;
+}
+// The same coordinate for the sample loops, which test it against the frame themselves: the pixel is inside
+// [0, n-1] exactly when (uint32_t)pixel_coord_raw(v) < n, and is then pixel_coord(v, n).  v_cvt_i32_f64 truncates,
+// saturates at the ends of int32 (below -1: negative, i.e. huge as unsigned; n and above: >= n) and turns NaN
+// into 0, which is the rule above without its three comparisons and two selects.  Checked against round() by the
+// device selftest next to pixel_coord.
+__device__ __forceinline__ int pixel_coord_raw(double v) {
+    const double x = v + copysign(0.49999999999999994, v);
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 // The sample enumeration of one scanline end-point pair (segment_3d/mod.rs:26-33,41-48):

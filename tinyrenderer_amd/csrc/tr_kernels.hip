@@ -82,6 +82,7 @@ struct SetupArgs {
     int per_corner;        // k_setup<false, false>: evaluate the vertex stage per corner instead of reading ndc / nout
     const double* bounds;  // per 64 consecutive triangles of the mesh: min xyz, max xyz of their positions (k_mesh_bounds),
                            // or nullptr; a context that owns a band drops whole clusters that project outside its rows
+    uint8_t* cull;         // per cluster of this draw: 1 = misses the band (written by k_cull_clusters), or nullptr
 };
 
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
@@ -94,7 +95,49 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
 // FUSED = true (draws of up to 256 workgroups of 64 to 256 threads): one launch does transform + setup + scan.
 // VIEWS (with FUSED = false): one launch sets up every (view, triangle) of a batch of views of one mesh; the vertex
 // stage is evaluated per corner under the view's matrices (as in the fused launch), prefix by the k_scan_* kernels.
-template <bool FUSED, bool VIEWS = false>
+// Band contexts (multi-GPU), draws whose mesh has cluster boxes (k_mesh_bounds): eight lanes take the corners of a
+// cluster's box through the vertex stage and the viewport; with w > 0 at all eight the projection of everything
+// inside the box lies between the corners' extremes, so a box that misses the band's rows by more than a pixel of
+// margin holds no triangle that could land a sample there: cull[cluster] = 1.  (One test per cluster here instead
+// of one per wave of k_setup, where 56 lanes idled through it: 110 -> 40 us for a band of a 10^7-triangle mesh.)
+__global__ __launch_bounds__(256) void k_cull_clusters(SetupArgs a, uint32_t n_clusters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cl = t >> 3, corner = t & 7u;
+    double y = 0.0;
+    bool ok = true;
+    if (cl < n_clusters) {
+        const double* b = a.bounds + 6 * (size_t)cl;
+        double g[4], v[4];
+        mat4_mul_vec4(a.pmv, b[(corner & 1u) ? 3 : 0], b[(corner & 2u) ? 4 : 1], b[(corner & 4u) ? 5 : 2], 1.0, g);
+        mat4_mul_vec4(a.vpm, g[0] / g[3], g[1] / g[3], g[2] / g[3], 1.0, v);
+        y = v[1] / v[3];
+        ok = g[3] > 1e-12 && fabs(y) < 1e15;  // (NaN fails both)
+    }
+    double ymin = y, ymax = y;
+    int all_ok = ok ? 1 : 0;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        ymin = fmin(ymin, __shfl_xor(ymin, d, 64));
+        ymax = fmax(ymax, __shfl_xor(ymax, d, 64));
+        all_ok &= __shfl_xor(all_ok, d, 64);
+    }
+    const bool miss = ceil(ymin - 1.5) > (double)(a.y_hi - 1) || floor(ymax + 1.5) < (double)a.y_lo;
+    const bool culled = all_ok && miss;  // (the same in the cluster's eight lanes)
+    if (corner == 0u && cl < n_clusters) a.cull[cl] = culled ? 1 : 0;
+    // k_setup writes nothing for a cluster dropped here; its small / mid flags, which the raster kernels sweep by
+    // frame position, are cleared now (8 of the 64 bytes per lane)
+    if (culled && cl < n_clusters && a.small_flag) {
+        uint8_t* f = a.small_flag + a.tri_base + (size_t)cl * 64u + corner * 8u;
+        const uint32_t left = (uint32_t)a.n_tris - (cl * 64u + corner * 8u);  // (may exceed 8, or be "negative")
+        if (cl * 64u + corner * 8u + 8u <= (uint32_t)a.n_tris && ((uintptr_t)f & 7u) == 0) {
+            *reinterpret_cast<uint2*>(f) = make_uint2(0u, 0u);
+        } else if (cl * 64u + corner * 8u < (uint32_t)a.n_tris) {
+            for (uint32_t i = 0; i < 8u && i < left; ++i) f[i] = 0;
+        }
+    }
+}
+
+template <bool FUSED, bool VIEWS = false, bool BAND = false>
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     if (VIEWS) {
         const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -112,41 +155,29 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) a.draw_table[a.draw] = a.params;
     uint32_t c0 = 0, c1 = 0;  // slots of my triangle's two halves
-    if (!FUSED && a.bounds && a.per_corner && (a.y_lo > 0 || a.y_hi < a.H)) {
-        // Band contexts (multi-GPU): the wave's 64 triangles are one cluster of the mesh.  Lanes 0..7 take the corners
-        // of its bounding box through the vertex stage and the viewport; with w > 0 at all eight the projection of
-        // everything inside the box lies between the corners' extremes, so a box that misses the band's rows by more
-        // than a pixel of margin holds no triangle that could land a sample there: the wave writes "nothing" for its
-        // triangles without reading one index or position (7/8 of a 10^7-triangle mesh on an 8-GPU node).
-        const int lane = threadIdx.x & 63;
-        const double* b = a.bounds + 6 * (size_t)((uint32_t)k >> 6);
-        double y = 0.0;
-        bool ok = true;
-        if (lane < 8 && (k - lane) < a.n_tris) {
-            double g[4], v[4];
-            mat4_mul_vec4(a.pmv, b[(lane & 1) ? 3 : 0], b[(lane & 2) ? 4 : 1], b[(lane & 4) ? 5 : 2], 1.0, g);
-            mat4_mul_vec4(a.vpm, g[0] / g[3], g[1] / g[3], g[2] / g[3], 1.0, v);
-            y = v[1] / v[3];
-            ok = g[3] > 1e-12 && fabs(y) < 1e15;  // (NaN fails both)
-        }
-        double ymin = y, ymax = y;
-#pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
-            ymin = fmin(ymin, __shfl_xor(ymin, d, 64));
-            ymax = fmax(ymax, __shfl_xor(ymax, d, 64));
-        }
-        const bool all_ok = (__ballot(ok) & 0xFFull) == 0xFFull;
-        const bool miss = ceil(ymin - 1.5) > (double)(a.y_hi - 1) || floor(ymax + 1.5) < (double)a.y_lo;
-        const bool skip = all_ok && __shfl((int)miss, 0, 64) != 0;
-        if (skip) {
-            if (k < a.n_tris) {
-                const uint32_t seq = a.tri_base + (uint32_t)k;
-                if (a.mode & 1) *reinterpret_cast<uint2*>(a.half_cnt + 2 * (size_t)seq) = make_uint2(0u, 0u);
-                if (a.small_flag) a.small_flag[seq] = 0;
-                if (a.mode & 8) a.need_shade[seq] = 0;
+    if (BAND) {
+        // Band contexts (multi-GPU): a fixed grid strides over the mesh's clusters of 64 triangles and sets up those whose
+        // box can reach the band's rows (k_cull_clusters); the others -- 7/8 of a 10^7-triangle mesh on an 8-GPU node --
+        // cost a byte each, read 64 turns ahead.  Nothing is written for them: the scan and k_build_shade consult the
+        // same bytes, their small_flag bytes were cleared by k_cull_clusters.
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+        const uint32_t n_clusters = ((uint32_t)a.n_tris + 63u) >> 6;
+        for (uint32_t c0 = wave_id; c0 < n_clusters; c0 += 64u * n_waves) {
+            const unsigned long long cl = (unsigned long long)c0 + (unsigned long long)lane * n_waves;
+            unsigned long long turns = __ballot(cl < n_clusters && a.cull[cl < n_clusters ? (uint32_t)cl : 0u] == 0);
+            while (turns) {
+                const uint32_t turn = (uint32_t)__ffsll((long long)turns) - 1u;
+                turns &= turns - 1ull;
+                const uint32_t kk = (c0 + turn * n_waves) * 64u + lane;
+                if (kk < (uint32_t)a.n_tris) {
+                    uint32_t d0 = 0, d1 = 0;
+                    setup_triangle(a, (int)kk, true, d0, d1, a.pmv, a.nmat, a.draw, a.tri_base + kk);
+                    if (a.mode & 1) *reinterpret_cast<uint2*>(a.half_cnt + 2 * (size_t)(a.tri_base + kk)) = make_uint2(d0, d1);
+                }
             }
-            return;
         }
+        return;
     }
     if (k < a.n_tris) {
         // (per_corner: a draw whose shade records are deferred needs no normals here and its positions once per
@@ -516,11 +547,32 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
 // get their TriShade now, from the vertex stage evaluated per corner -- the arithmetic of k_transform, so the bits
 // are those the eager path would have written.  A 10^7-triangle mesh has a few million such triangles: the others
 // never cost 256 B of record traffic.
+__device__ __forceinline__ void build_shade_record(const SetupArgs& a, uint32_t k);
+template <bool BAND>
 __global__ __launch_bounds__(256) void k_build_shade(SetupArgs a, const uint8_t* __restrict__ need_shade) {
+    if (BAND) {  // a band context: a fixed grid over the clusters k_cull_clusters kept (as in k_setup)
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+        const uint32_t n_clusters = ((uint32_t)a.n_tris + 63u) >> 6;
+        for (uint32_t c0 = wave_id; c0 < n_clusters; c0 += 64u * n_waves) {
+            const unsigned long long cl = (unsigned long long)c0 + (unsigned long long)lane * n_waves;
+            unsigned long long turns = __ballot(cl < n_clusters && a.cull[cl < n_clusters ? (uint32_t)cl : 0u] == 0);
+            while (turns) {
+                const uint32_t turn = (uint32_t)__ffsll((long long)turns) - 1u;
+                turns &= turns - 1ull;
+                const uint32_t kk = (c0 + turn * n_waves) * 64u + lane;
+                if (kk < (uint32_t)a.n_tris && need_shade[a.tri_base + kk]) build_shade_record(a, kk);
+            }
+        }
+        return;
+    }
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (uint32_t)a.n_tris) return;
+    if (!need_shade[a.tri_base + k]) return;
+    build_shade_record(a, k);
+}
+__device__ __forceinline__ void build_shade_record(const SetupArgs& a, uint32_t k) {
     const uint32_t seq = a.tri_base + k;
-    if (!need_shade[seq]) return;
     const uint32_t* ix = a.idx + 9 * (size_t)k;
     const uint32_t iv[3] = {ix[0], ix[3], ix[6]};
     const uint32_t it[3] = {ix[1], ix[4], ix[7]};
@@ -539,6 +591,8 @@ __global__ __launch_bounds__(256) void k_build_shade(SetupArgs a, const uint8_t*
     }
     a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, true, a.nmat, a.draw);
 }
+template __global__ void k_build_shade<false>(SetupArgs, const uint8_t*);
+template __global__ void k_build_shade<true>(SetupArgs, const uint8_t*);
 
 // Bounding boxes of the mesh's clusters of 64 consecutive triangles (object space), once per mesh (tr_mesh_create):
 // bounds[6 c .. 6 c + 5] = min x, y, z, max x, y, z over the positions the cluster's triangles index.
@@ -602,7 +656,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total_
 
 // (Thread t of a tile takes entries [16 t, 16 t + 16) as four 16-byte loads when the arrays allow it: a lane that
 // reads its 64 bytes one word at a time makes every load instruction of the wave touch 64 different lines.)
-__device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, uint32_t begin, uint32_t n, uint32_t v[kScanPer]) {
+__device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, uint32_t begin, uint32_t n, uint32_t v[kScanPer],
+                                            const uint8_t* __restrict__ cull = nullptr) {
+    // (a thread's 16 halves are 8 triangles of one cluster: a culled cluster's counts are zero and were never written)
+    if (cull && begin < n && cull[begin >> 7]) {
+#pragma unroll
+        for (int i = 0; i < kScanPer; ++i) v[i] = 0u;
+        return;
+    }
     if (begin + kScanPer <= n && ((uintptr_t)(cnt + begin) & 15u) == 0) {
 #pragma unroll
         for (int q = 0; q < kScanPer / 4; ++q) {
@@ -615,13 +676,30 @@ __device__ __forceinline__ void scan_load16(const uint32_t* __restrict__ cnt, ui
     }
 }
 
+// (cull: the draw's cluster bytes of a band context, or nullptr.  A tile is the 4 096 halves of 32 clusters; when
+// k_cull_clusters dropped all of them, every count is zero and the tile is neither read here nor in k_scan_apply.)
+__device__ __forceinline__ bool scan_tile_is_dead(const uint8_t* __restrict__ cull, uint32_t n_clusters, uint32_t tile) {
+    if (!cull) return false;
+    int alive = 0;
+    if (threadIdx.x < (uint32_t)(kScanTile / 128)) {
+        const uint32_t cl = tile * (uint32_t)(kScanTile / 128) + threadIdx.x;
+        alive = (cl < n_clusters && cull[cl] == 0) ? 1 : 0;
+    }
+    return __syncthreads_or(alive) == 0;
+}
+
 __global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const uint32_t* __restrict__ cnt,
                                                                  uint32_t n,
-                                                                 unsigned long long* tile_sum) {
+                                                                 unsigned long long* tile_sum,
+                                                                 const uint8_t* __restrict__ cull, uint32_t n_clusters) {
     uint32_t tile = blockIdx.x;
+    if (scan_tile_is_dead(cull, n_clusters, tile)) {
+        if (threadIdx.x == 0) tile_sum[tile] = 0ull;
+        return;
+    }
     uint32_t begin = tile * kScanTile + threadIdx.x * kScanPer;
     uint32_t v[kScanPer];
-    scan_load16(cnt, begin, n, v);
+    scan_load16(cnt, begin, n, v, cull);
     unsigned long long s = 0;
 #pragma unroll
     for (int i = 0; i < kScanPer; ++i) s += v[i];
@@ -638,50 +716,68 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const uint32_t*
     }
 }
 
-// single block: tile_sum -> exclusive tile bases (u64, in place), starting at *carry_in
+// single block: tile_sum -> exclusive tile bases (u64, in place), starting at *carry_in.  Thread t owns a run of
+// consecutive tiles: one pass, one block scan of the runs' totals (20 rounds of four barriers each took 15 us for the
+// 4 984 tiles of a 10^7-triangle draw).
 __global__ __launch_bounds__(kScanThreads) void k_scan_tile_bases(unsigned long long* tile_sum,
                                                                   uint32_t n_tiles,
                                                                   const uint32_t* carry_in,
                                                                   uint32_t* flags) {
-    __shared__ unsigned long long run;
     __shared__ unsigned long long wtot[kScanThreads / 64];
-    if (threadIdx.x == 0) run = *carry_in;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += kScanThreads) {
-        uint32_t i = base + threadIdx.x;
-        unsigned long long v = i < n_tiles ? tile_sum[i] : 0ull;
-        unsigned long long inc = v;
-        int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    unsigned long long mine = 0;
+    for (uint32_t i = lo; i < hi; ++i) mine += tile_sum[i];
+    unsigned long long inc = mine;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            unsigned long long t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        unsigned long long b = run, tot = 0;
-        for (int k = 0; k < kScanThreads / 64; ++k) {
-            if (k < w) b += wtot[k];
-            tot += wtot[k];
-        }
-        if (i < n_tiles) tile_sum[i] = b + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 0) run += tot;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
     }
-    if (threadIdx.x == 0 && run > 0xFFFFFFFFull) atomicOr(flags, 1u << 4);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    unsigned long long b = *carry_in, tot = *carry_in;
+    for (int k = 0; k < kScanThreads / 64; ++k) {
+        if (k < w) b += wtot[k];
+        tot += wtot[k];
+    }
+    unsigned long long run = b + inc - mine;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const unsigned long long v = tile_sum[i];
+        tile_sum[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0 && tot > 0xFFFFFFFFull) atomicOr(flags, 1u << 4);
 }
 
 // per tile: exclusive scan with the tile base (tile_base == nullptr: single tile, base = off[0])
 __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __restrict__ cnt,
                                                              uint32_t n, uint32_t* off,
                                                              const unsigned long long* tile_base,
-                                                             uint32_t* flags) {
+                                                             uint32_t* flags,
+                                                             const uint8_t* __restrict__ cull, uint32_t n_clusters) {
     uint32_t tile = blockIdx.x;
     uint32_t begin = tile * kScanTile + threadIdx.x * kScanPer;
     uint32_t v[kScanPer];
     uint32_t s = 0;
-    scan_load16(cnt, begin, n, v);
+    if (scan_tile_is_dead(cull, n_clusters, tile)) {
+        // every entry of the tile is the tile's base, and so is the entry in front of it (the previous tile's last):
+        // whole aligned 16-byte groups, a lane beside its neighbour, plus the tile's own last entry
+        const uint32_t base32 = (uint32_t)(tile_base ? tile_base[tile] : (unsigned long long)off[0]);
+        const uint32_t t0 = tile * kScanTile;
+        if (t0 + kScanTile <= n && ((uintptr_t)(off + t0) & 15u) == 0) {
+#pragma unroll
+            for (int q = 0; q < kScanPer / 4; ++q)
+                reinterpret_cast<uint4*>(off + t0)[threadIdx.x + q * kScanThreads] = make_uint4(base32, base32, base32, base32);
+            if (threadIdx.x == 0) off[t0 + kScanTile] = base32;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < kScanPer; ++i) v[i] = 0u;
+    } else {
+        scan_load16(cnt, begin, n, v, cull);
+    }
 #pragma unroll
     for (int i = 0; i < kScanPer; ++i) s += v[i];
     uint32_t tot;
@@ -983,6 +1079,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     // 2: 30.7, 4 at 82 VGPRs: 31.2)
     constexpr int kBatch = PASS == 0 ? 1 : 3;
     const int lane = threadIdx.x & 63;
+    const uint32_t band_rows = (uint32_t)(a.y_hi - a.y_lo);
     const bool wave0 = threadIdx.x < 64;
     const uint32_t s_begin = a.half_off[a.h_lo];
     const uint32_t s_end = a.half_off[a.h_hi];
@@ -1149,15 +1246,17 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                     const double x = r[0] + sp * r[3];
                     const double y = r[1] + sp * r[4];
                     const double z = r[2] + sp * r[5];
-                    const int ix = pixel_coord(x, a.W);
-                    const int iy = pixel_coord(y, a.H);
-                    const bool inb = ix >= 0 && iy >= a.y_lo && iy < a.y_hi;
+                    const int ix = pixel_coord_raw(x);
+                    const int iy = pixel_coord_raw(y);
+                    const bool inb = (uint32_t)ix < (uint32_t)a.W && (uint32_t)(iy - a.y_lo) < band_rows;
                     if (PASS == 0) {
                         // counted per wave (a vote and a scalar population count instead of two
                         // 64-bit adds in every lane); the totals are taken from lane 0 at the end
                         const bool counted = chunk * 64u + sidx >= s_count;
+#ifndef TR_COUNT_ACT
                         cnt_samples += (uint32_t)__popcll(__ballot(counted));
                         cnt_inb += (uint32_t)__popcll(__ballot(counted && inb));
+#endif
                     }
                     if (inb) {
                         const double dist = -z;
@@ -1197,6 +1296,13 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                 }
             }
             bool rare = false;
+#ifdef TR_COUNT_ACT  // (diagnostic build: "samples" = wave-instructions with an atomic, "fragments" = lanes with one)
+            if (PASS == 0) {
+                const unsigned long long m = __ballot(act[0]);
+                cnt_samples += m ? 1u : 0u;
+                cnt_inb += (uint32_t)__popcll(m);
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < kBatch; ++u) {
                 if (PASS == 0) {
@@ -1288,8 +1394,15 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t u_lo = a.h_lo >> 6, u_hi = (uint32_t)(((unsigned long long)a.h_hi + 63ull) >> 6);
-    for (uint32_t u = u_lo + wave_id; u < u_hi; u += n_waves) {
-        if (a.small_grp[u] == 0) continue;  // (the same byte for every lane)
+    // (lane l looks up the group of the wave's l-th next turn: one load per 64 turns instead of a dependent load per
+    // turn, which is what a band context's walk past its empty groups consisted of)
+    for (uint32_t u0 = u_lo + wave_id; u0 < u_hi; u0 += 64u * n_waves) {
+        const unsigned long long ul = (unsigned long long)u0 + (unsigned long long)lane * n_waves;
+        unsigned long long turns = __ballot(ul < u_hi && a.small_grp[ul < u_hi ? (uint32_t)ul : u_lo] != 0);
+      while (turns) {
+        const uint32_t turn = (uint32_t)__ffsll((long long)turns) - 1u;
+        turns &= turns - 1ull;
+        const uint32_t u = u0 + turn * n_waves;
         const uint32_t h = u * 64u + lane;
         if (h < a.h_lo || h >= a.h_hi) continue;
         if (a.small_flag[h >> 1] != 1) continue;  // (a byte per triangle: the other triangles' records are not touched)
@@ -1383,6 +1496,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
         flush(p0, e0);
         flush(p1, e1);
         if (PASS == 0) half_live[h] = live ? 1 : 0;
+      }
     }
     if (PASS == 0) {
 #pragma unroll
@@ -1557,6 +1671,7 @@ template __global__ void k_mid<1, false>(RasterArgs, uint8_t*);
 template __global__ void k_setup<false, false>(SetupArgs);
 template __global__ void k_setup<true, false>(SetupArgs);
 template __global__ void k_setup<false, true>(SetupArgs);
+template __global__ void k_setup<false, false, true>(SetupArgs);
 template __global__ void k_raster<0, true, false, 128, true>(RasterArgs);
 template __global__ void k_raster<1, false, false, 128, true>(RasterArgs);
 template __global__ void k_raster<0, true, false, 256, true>(RasterArgs);
@@ -1987,6 +2102,15 @@ __global__ __launch_bounds__(256) void k_selftest(unsigned long long seed, uint3
         bad2 += pixel_coord(near, 4096) != pixel_coord_by_round(near, 4096) ? 1 : 0;
         bad2 += pixel_coord(num, 4096) != pixel_coord_by_round(num, 4096) ? 1 : 0;
         bad2 += pixel_coord(fx * 4100.0 - 2.0, 4096) != pixel_coord_by_round(fx * 4100.0 - 2.0, 4096) ? 1 : 0;
+        {   // the sample loops' form: inside exactly when the raw value is below n as an unsigned number
+            const double vs[3] = {near, num, fx * 4100.0 - 2.0};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int raw = pixel_coord_raw(vs[q]);
+                const int viaraw = (uint32_t)raw < 4096u ? raw : -1;
+                bad2 += viaraw != pixel_coord_by_round(vs[q], 4096) ? 1 : 0;
+            }
+        }
     }
     if (bad0) atomicAdd(&out[0], bad0);
     if (bad1) atomicAdd(&out[1], bad1);
