@@ -385,7 +385,6 @@ Mat4 viewport_matrix(int W, int H) {
 }
 
 // The scanline prefix of halves [lo, lo + n_halves), continuing from the previous draw's total.
-constexpr unsigned kBandSetupBlocks = 8192;  // grid of k_setup / k_build_shade in a band context (256 threads each)
 int launch_scan(tr_context* c, uint32_t lo, uint32_t n_halves, const uint8_t* cull = nullptr) {
     const uint32_t n_clusters = (n_halves / 2u + 63u) / 64u;  // (of the draw whose halves these are, when `cull` is given)
     uint32_t tiles = (n_halves + kScanTile - 1) / kScanTile;
@@ -1219,10 +1218,8 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
                 const uint32_t n_clusters = (uint32_t)(((size_t)mesh->n_tris + 63) / 64);
                 hipLaunchKernelGGL(k_cull_clusters, dim3((n_clusters * 8u + 255u) / 256u), dim3(256), 0, c->stream, sa, n_clusters);
                 TR_HIP(c, hipGetLastError());
-                if (blocks > kBandSetupBlocks) blocks = kBandSetupBlocks;  // a fixed grid strides over the clusters kept
             }
-            if (sa.cull) hipLaunchKernelGGL((k_setup<false, false, true>), dim3(blocks), dim3(256), 0, c->stream, sa);
-            else hipLaunchKernelGGL((k_setup<false>), dim3(blocks), dim3(256), 0, c->stream, sa);
+            hipLaunchKernelGGL((k_setup<false>), dim3(blocks), dim3(256), 0, c->stream, sa);
         }
         TR_HIP(c, hipGetLastError());
         if (c->mode != 1 && !fused) {
@@ -1492,9 +1489,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             SetupArgs ba = d.sa;
             ba.rast = c->rast; ba.shade = c->shade;  // (the arrays may have grown since the draw)
             unsigned blocks = (unsigned)((ba.n_tris + 255) / 256);
-            if (ba.cull && blocks > kBandSetupBlocks) blocks = kBandSetupBlocks;
-            if (ba.cull) hipLaunchKernelGGL(k_build_shade<true>, dim3(blocks), dim3(256), 0, c->stream, ba, c->need_shade);
-            else hipLaunchKernelGGL(k_build_shade<false>, dim3(blocks), dim3(256), 0, c->stream, ba, c->need_shade);
+            hipLaunchKernelGGL(k_build_shade, dim3(blocks), dim3(256), 0, c->stream, ba, c->need_shade);
             TR_HIP(c, hipGetLastError());
         }
     }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_cull_clusters(SetupArgs a, uint32_t n_c
     }
 }
 
-template <bool FUSED, bool VIEWS = false, bool BAND = false>
+template <bool FUSED, bool VIEWS = false>
 __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     if (VIEWS) {
         const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,30 +155,11 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) a.draw_table[a.draw] = a.params;
     uint32_t c0 = 0, c1 = 0;  // slots of my triangle's two halves
-    if (BAND) {
-        // Band contexts (multi-GPU): a fixed grid strides over the mesh's clusters of 64 triangles and sets up those whose
-        // box can reach the band's rows (k_cull_clusters); the others -- 7/8 of a 10^7-triangle mesh on an 8-GPU node --
-        // cost a byte each, read 64 turns ahead.  Nothing is written for them: the scan and k_build_shade consult the
-        // same bytes, their small_flag bytes were cleared by k_cull_clusters.
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-        const uint32_t n_clusters = ((uint32_t)a.n_tris + 63u) >> 6;
-        for (uint32_t c0 = wave_id; c0 < n_clusters; c0 += 64u * n_waves) {
-            const unsigned long long cl = (unsigned long long)c0 + (unsigned long long)lane * n_waves;
-            unsigned long long turns = __ballot(cl < n_clusters && a.cull[cl < n_clusters ? (uint32_t)cl : 0u] == 0);
-            while (turns) {
-                const uint32_t turn = (uint32_t)__ffsll((long long)turns) - 1u;
-                turns &= turns - 1ull;
-                const uint32_t kk = (c0 + turn * n_waves) * 64u + lane;
-                if (kk < (uint32_t)a.n_tris) {
-                    uint32_t d0 = 0, d1 = 0;
-                    setup_triangle(a, (int)kk, true, d0, d1, a.pmv, a.nmat, a.draw, a.tri_base + kk);
-                    if (a.mode & 1) *reinterpret_cast<uint2*>(a.half_cnt + 2 * (size_t)(a.tri_base + kk)) = make_uint2(d0, d1);
-                }
-            }
-        }
-        return;
-    }
+    // Band contexts (multi-GPU): the wave's 64 triangles are one cluster of the mesh, and k_cull_clusters found that its
+    // box misses the band's rows: nothing of theirs is read, nothing written (the scan and k_build_shade consult the
+    // same byte, the small / mid flags were cleared by k_cull_clusters) -- 7/8 of a 10^7-triangle mesh on an 8-GPU node.
+    // (A fixed grid striding over the clusters kept was no faster: the hoisted matrices cost it a wave per SIMD.)
+    if (!FUSED && a.cull && a.cull[(uint32_t)k >> 6]) return;
     if (k < a.n_tris) {
         // (per_corner: a draw whose shade records are deferred needs no normals here and its positions once per
         // corner: the vertex stage is evaluated in place, there is no k_transform launch and no ndc array)
@@ -548,26 +529,10 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
 // are those the eager path would have written.  A 10^7-triangle mesh has a few million such triangles: the others
 // never cost 256 B of record traffic.
 __device__ __forceinline__ void build_shade_record(const SetupArgs& a, uint32_t k);
-template <bool BAND>
 __global__ __launch_bounds__(256) void k_build_shade(SetupArgs a, const uint8_t* __restrict__ need_shade) {
-    if (BAND) {  // a band context: a fixed grid over the clusters k_cull_clusters kept (as in k_setup)
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-        const uint32_t n_clusters = ((uint32_t)a.n_tris + 63u) >> 6;
-        for (uint32_t c0 = wave_id; c0 < n_clusters; c0 += 64u * n_waves) {
-            const unsigned long long cl = (unsigned long long)c0 + (unsigned long long)lane * n_waves;
-            unsigned long long turns = __ballot(cl < n_clusters && a.cull[cl < n_clusters ? (uint32_t)cl : 0u] == 0);
-            while (turns) {
-                const uint32_t turn = (uint32_t)__ffsll((long long)turns) - 1u;
-                turns &= turns - 1ull;
-                const uint32_t kk = (c0 + turn * n_waves) * 64u + lane;
-                if (kk < (uint32_t)a.n_tris && need_shade[a.tri_base + kk]) build_shade_record(a, kk);
-            }
-        }
-        return;
-    }
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= (uint32_t)a.n_tris) return;
+    if (a.cull && a.cull[k >> 6]) return;  // (a band context: the cluster misses its rows, the same byte for the whole wave)
     if (!need_shade[a.tri_base + k]) return;
     build_shade_record(a, k);
 }
@@ -591,8 +556,6 @@ __device__ __forceinline__ void build_shade_record(const SetupArgs& a, uint32_t 
     }
     a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, true, a.nmat, a.draw);
 }
-template __global__ void k_build_shade<false>(SetupArgs, const uint8_t*);
-template __global__ void k_build_shade<true>(SetupArgs, const uint8_t*);
 
 // Bounding boxes of the mesh's clusters of 64 consecutive triangles (object space), once per mesh (tr_mesh_create):
 // bounds[6 c .. 6 c + 5] = min x, y, z, max x, y, z over the positions the cluster's triangles index.
@@ -1671,7 +1634,6 @@ template __global__ void k_mid<1, false>(RasterArgs, uint8_t*);
 template __global__ void k_setup<false, false>(SetupArgs);
 template __global__ void k_setup<true, false>(SetupArgs);
 template __global__ void k_setup<false, true>(SetupArgs);
-template __global__ void k_setup<false, false, true>(SetupArgs);
 template __global__ void k_raster<0, true, false, 128, true>(RasterArgs);
 template __global__ void k_raster<1, false, false, 128, true>(RasterArgs);
 template __global__ void k_raster<0, true, false, 256, true>(RasterArgs);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One tile-row band of BASELINE.json configs[3] (african_head subdivided 6x at 7680x4320), rendered a few times:
 for `rocprofv3 --kernel-trace --stats` of what a rank of the band-sharded job runs per frame.
-    python tools/band_one.py [band=3] [n_bands=8] [levels=6] [frames=6]"""
+    python tools/band_one.py [band=3] [n_bands=8] [levels=6] [frames=6] [y_lo y_hi]     (y_lo y_hi: these rows instead)"""
 import os
 import sys
 import time
@@ -21,6 +21,8 @@ def main():
     W, H, draws = B.head_subdivided(levels, 7680, 4320)
     st = ModelRendererState(W, H)
     y_lo, y_hi = sharding.band_rows(H, band, n_bands)
+    if len(a) >= 6:
+        y_lo, y_hi = a[4], a[5]
     times = []
     for _ in range(frames):
         st.synchronize()
