@@ -23,6 +23,7 @@ pub const TR_FLAG_NEG_INF_DEPTH: u32 = 1 << 3;
 pub const TR_FLAG_SCANLINE_OVERFLOW: u32 = 1 << 4;
 pub const TR_FLAG_NAN_PIXEL_OVERFLOW: u32 = 1 << 5;
 pub const TR_FLAG_BIN_OVERFLOW: u32 = 1 << 6;
+pub const TR_FLAG_PREFIX_STALL: u32 = 1 << 7;
 
 pub const TR_RASTER_GLOBAL: c_int = 0;
 pub const TR_RASTER_TILE: c_int = 1;

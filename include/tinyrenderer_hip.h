@@ -55,9 +55,12 @@ enum {
     TR_FLAG_SCANLINE_OVERFLOW = 1u << 4, /* more than 2^32-1 scanlines in one frame */
     TR_FLAG_NAN_PIXEL_OVERFLOW = 1u << 5, /* more NaN-depth pixels than the side table holds
                                              (global-atomic raster mode only) */
-    TR_FLAG_BIN_OVERFLOW = 1u << 6  /* transient (tile / row raster): a bin list was too small; tr_resolve
+    TR_FLAG_BIN_OVERFLOW = 1u << 6, /* transient (tile / row raster): a bin list was too small; tr_resolve
                                        itself grows it, redoes the resolve and clears the bit before it
                                        returns (one host wait per resolve in those two modes) */
+    TR_FLAG_PREFIX_STALL = 1u << 7  /* internal error, never seen in practice: a workgroup of the fused set-up launch
+                                       gave up waiting for the scanline prefix of the workgroups before it (a bounded
+                                       poll instead of a hang); the frame is incomplete */
 };
 
 /* Raster strategies (same results, bit for bit). */

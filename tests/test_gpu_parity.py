@@ -827,3 +827,33 @@ def test_context_lifecycle_leaves_no_device_memory_behind(oracle):
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     free1 = free_bytes()
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned"
+
+
+def test_fused_setup_prefix_poll_gives_up_instead_of_hanging(oracle, monkeypatch):
+    """k_setup<true> polls the slot totals of the workgroups before it; a word that never shows the launch's tag must end
+    in TR_FLAG_PREFIX_STALL after a bounded number of polls, not in a hang (TR_DEBUG_PREFIX_STALL makes the pollers wait
+    for a tag nobody publishes).  The context works again in the next frame of a context created without the switch."""
+    import time
+
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 320, 180
+    draws = _head_scene(W, Hh, with_eye=False)
+    monkeypatch.setenv("TR_DEBUG_PREFIX_STALL", "1")
+    st = ModelRendererState(W, Hh)
+    try:
+        t0 = time.perf_counter()
+        clear_screen(st)
+        for d in draws:
+            render_mesh_component(st, *d)
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        st.synchronize()
+        assert time.perf_counter() - t0 < 20.0
+        assert st.status_flags() & _ffi.TR_FLAG_PREFIX_STALL
+    finally:
+        st.close()
+    monkeypatch.delenv("TR_DEBUG_PREFIX_STALL")
+    g = SU.gpu_render(W, Hh, draws)
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    assert np.array_equal(g["present"], o["present"]) and np.array_equal(g["key"], o["key"])

@@ -26,6 +26,7 @@ TR_FLAG_NEG_INF_DEPTH = 1 << 3
 TR_FLAG_SCANLINE_OVERFLOW = 1 << 4
 TR_FLAG_NAN_PIXEL_OVERFLOW = 1 << 5
 TR_FLAG_BIN_OVERFLOW = 1 << 6
+TR_FLAG_PREFIX_STALL = 1 << 7
 TR_RASTER_GLOBAL, TR_RASTER_TILE, TR_RASTER_ROWS = 0, 1, 2
 TR_LAYOUT_ROW_MAJOR = 0
 TR_LAYOUT_REFERENCE = 1

@@ -94,6 +94,7 @@ struct tr_context {
     uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
     uint8_t* half_live = nullptr;    // small-triangle path: per half, may hold a winner (2 x tri_cap bytes)
     uint8_t* small_grp = nullptr;    // per 32 triangles: some triangle of the group is small (tri_cap / 32 + 1 bytes)
+    bool debug_prefix_stall = false; // TR_DEBUG_PREFIX_STALL (tests): force the bounded poll of the fused set-up launch to give up
     uint8_t* cluster_cull = nullptr; // band contexts: a byte per 64-triangle cluster of the frame's big draws (k_cull_clusters)
     size_t cull_cap = 0, cull_used = 0;
     uint8_t* need_shade = nullptr;   // deferred shade records: per triangle, flagged by the winner pass (tri_cap bytes)
@@ -734,6 +735,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (const char* e = std::getenv("TR_MID_PX")) c->mid_px = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_MID_SAMPLES")) c->mid_samples = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = std::getenv("TR_DEBUG_PREFIX_STALL")) c->debug_prefix_stall = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_DEFER_SHADE")) c->defer_tris = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char* e = std::getenv("TR_SCAN_RECORDS")) {
         c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
@@ -1200,6 +1202,12 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.nrm = mesh->nrm; sa.pmv = pmv; sa.ticket = c->ticket; sa.half_off = c->half_off;
         if (++c->scan_tag == 0) c->scan_tag = 1;
         sa.scan_tag = c->scan_tag;
+        sa.scan_expect = c->scan_tag;
+        sa.spin_limit = 1u << 24;
+        if (c->debug_prefix_stall) {  // (tests only: the pollers wait for a tag nobody publishes)
+            sa.scan_expect = c->scan_tag ^ 0x40000000u;
+            sa.spin_limit = 1u << 10;
+        }
         sa.scan_lo = 2u * tri_base; sa.n_halves = n_halves;
         sa.views = nullptr; sa.n_views = 0;
         if (defer) {

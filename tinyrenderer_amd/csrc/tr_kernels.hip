@@ -73,6 +73,8 @@ struct SetupArgs {
     Mat4 pmv;              // perspective * model_view
     uint32_t* ticket;      // 256 words of 8 bytes: {scan_tag, slot total} of each workgroup of the fused launch
     uint32_t scan_tag;     // differs from launch to launch (never 0)
+    uint32_t scan_expect;  // the tag the pollers wait for: scan_tag (TR_DEBUG_PREFIX_STALL: another one, so that the test sees the bail-out)
+    uint32_t spin_limit;   // polls of one word before a workgroup gives up (2^24)
     uint32_t* half_off;    // prefix to write: half_off[scan_lo + 1 .. scan_lo + n_halves]
     uint32_t scan_lo, n_halves;
     // batched views (k_setup<false, true>): thread g = view * n_tris + k sets up triangle k of the mesh under
@@ -212,9 +214,9 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
             uint32_t tries = 0;
             for (;;) {
                 word = __hip_atomic_load(&agg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(word >> 32) == a.scan_tag) break;
-                if (++tries > (1u << 24)) {  // (seconds: something is badly wrong; leave with the overflow flag rather than hang)
-                    atomicOr(a.flags, 1u << 4);
+                if ((uint32_t)(word >> 32) == a.scan_expect) break;
+                if (++tries > a.spin_limit) {  // (2^24 tries = seconds: something is badly wrong; leave with TR_FLAG_PREFIX_STALL rather than hang)
+                    atomicOr(a.flags, 1u << 7);
                     word = 0;
                     break;
                 }
