@@ -857,3 +857,32 @@ def test_fused_setup_prefix_poll_gives_up_instead_of_hanging(oracle, monkeypatch
     g = SU.gpu_render(W, Hh, draws)
     o = SU.oracle_render(oracle, W, Hh, draws)
     assert np.array_equal(g["present"], o["present"]) and np.array_equal(g["key"], o["key"])
+
+
+def test_boxed_shade_launch_follows_what_moves(oracle):
+    """The cheap resolve launches only the blocks of the frame's screen box plus the box the previous launch painted:
+    one context, frames whose content moves, shrinks, vanishes and comes back must each equal the oracle's image
+    (nothing stale outside the new box, nothing missing inside it)."""
+    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 640, 360
+    head = _head_scene(W, Hh, with_eye=False)
+    eye_mc = SU.component("eye_inner")
+    eye_left = [(eye_mc, scenes.shader_for(eye_mc, W, Hh, eye=(0.9, 0.1, 1.0)))]
+    eye_right = [(eye_mc, scenes.shader_for(eye_mc, W, Hh, eye=(-0.9, -0.2, 1.0)))]
+    st = ModelRendererState(W, Hh)
+    try:
+        for n, draws in enumerate((head, eye_left, eye_right, [], eye_left, head, [])):
+            clear_screen(st)
+            for d in draws:
+                render_mesh_component(st, *d)
+            got = st.present()
+            if draws:
+                want = SU.oracle_render(oracle, W, Hh, draws)["present"]
+            else:
+                want = np.zeros((Hh, W, 4), dtype=np.uint8)
+                want[..., 3] = 255
+            assert np.array_equal(got, want), n
+            assert st.status_flags() == 0
+    finally:
+        st.close()

@@ -47,6 +47,19 @@ struct tr_mesh {
     double* bounds = nullptr;  // meshes of 65 536 triangles or more: a box per 64 consecutive triangles (k_mesh_bounds)
     int64_t n_pos = 0, n_nrm = 0, n_uvw = 0, n_tris = 0;
     bool any_uv = false;
+    double box[6] = {0, 0, 0, 0, 0, 0};  // min xyz, max xyz of the positions (host, at creation)
+    bool box_ok = false;                 // false: a position is not finite (the frame's screen box is then the whole frame)
+};
+
+// Pixel rectangle [x0, x1) x [y0, y1)
+struct PixBox {
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    bool empty() const { return x0 >= x1 || y0 >= y1; }
+    void add(const PixBox& o) {
+        if (o.empty()) return;
+        if (empty()) { *this = o; return; }
+        x0 = std::min(x0, o.x0); y0 = std::min(y0, o.y0); x1 = std::max(x1, o.x1); y1 = std::max(y1, o.y1);
+    }
 };
 
 enum { ST_CLEAR = 0, ST_TRANSFORM, ST_SETUP, ST_DEPTH, ST_WINNER, ST_SHADE, ST_COUNT };
@@ -56,6 +69,9 @@ struct tr_context {
     int W = 0, H = 0;
     int y_lo = 0, y_hi = 0;
     int shaded_lo = 0, shaded_hi = 0;  // rows the last shade launch covered (a band context shades its band's rows only)
+    PixBox frame_box;   // where this frame's draws can land a sample (projected mesh boxes, a margin added); tr_clear empties it
+    PixBox paint_box;   // where the colour plane may differ from the background after the last shade launch
+    bool shade_box = true;  // TR_SHADE_BOX: the cheap resolve launches the blocks of frame_box + paint_box only
     // batched views (tr_create_views / tr_render_views): the planes hold max_views slices of W x H pixels
     int max_views = 1;
     int n_views = 1;                 // slices the current frame covers (1 unless the frame is a tr_render_views batch)
@@ -714,6 +730,8 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     c->y_hi = height;
     c->shaded_lo = 0;
     c->shaded_hi = height;
+    c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = width; c->paint_box.y1 = height;
+    if (const char* e = std::getenv("TR_SHADE_BOX")) c->shade_box = std::atoi(e) != 0;
     c->max_views = max_views;
     c->n_views = max_views;  // (an empty frame resolves every slice)
     c->npix_all = (size_t)width * height * (size_t)max_views;
@@ -895,6 +913,7 @@ int tr_clear(tr_context* c) {
     c->frame_textures.clear();
     c->frame_lost_texture = false;
     c->deferred.clear();
+    c->frame_box = PixBox();
     c->cull_used = 0;
     c->frame_lost_mesh = false;
     if (c->small_any)  // the per-group summary of the small triangles restarts with the frame
@@ -934,6 +953,19 @@ int tr_mesh_create(tr_context* c, const double* positions, int64_t n_positions, 
     if (!m) return fail(c, TR_ERR_OOM, "host allocation failed");
     m->n_pos = n_positions; m->n_nrm = n_normals; m->n_uvw = n_uvw; m->n_tris = n_triangles;
     m->any_uv = any_uv;
+    {
+        bool ok = n_positions > 0;
+        double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int64_t i = 0; i < n_positions && ok; ++i)
+            for (int d = 0; d < 3; ++d) {
+                const double v = positions[3 * i + d];
+                if (!std::isfinite(v)) { ok = false; break; }
+                if (i == 0 || v < lo[d]) lo[d] = v;
+                if (i == 0 || v > hi[d]) hi[d] = v;
+            }
+        m->box_ok = ok;
+        for (int d = 0; d < 3; ++d) { m->box[d] = lo[d]; m->box[3 + d] = hi[d]; }
+    }
     auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         size_t alloc = bytes ? bytes : 8;
         hipError_t e = hipMalloc(dst, alloc);
@@ -1068,6 +1100,38 @@ void tr_shadow_map_destroy(tr_shadow_map* m) {
     delete m;
 }
 
+// Where a draw of `mesh` under `pmv` can land a sample: the mesh box's eight corners through the vertex stage and the
+// viewport (the arithmetic of k_cull_clusters, on the host).  With w > 0 at all eight, everything inside the box
+// projects between the corners' extremes and a triangle's samples lie inside the triangle; two pixels of margin cover
+// the rounding.  Anything doubtful gives the whole frame.
+static PixBox draw_pix_box(const tr_context* c, const tr_mesh* mesh, const double pmv[16]) {
+    PixBox full;
+    full.x1 = c->W; full.y1 = c->H;
+    if (!mesh->box_ok) return full;
+    const Mat4 vpm = viewport_matrix(c->W, c->H);
+    double xmin = 0, xmax = 0, ymin = 0, ymax = 0;
+    for (int k = 0; k < 8; ++k) {
+        const double q[3] = {mesh->box[(k & 1) ? 3 : 0], mesh->box[(k & 2) ? 4 : 1], mesh->box[(k & 4) ? 5 : 2]};
+        double g[4], v[4];
+        for (int r = 0; r < 4; ++r) g[r] = pmv[r] * q[0] + pmv[4 + r] * q[1] + pmv[8 + r] * q[2] + pmv[12 + r];
+        if (!(g[3] > 1e-9)) return full;
+        const double n[3] = {g[0] / g[3], g[1] / g[3], g[2] / g[3]};
+        for (int r = 0; r < 4; ++r) v[r] = vpm.m[r] * n[0] + vpm.m[4 + r] * n[1] + vpm.m[8 + r] * n[2] + vpm.m[12 + r];
+        const double px = v[0] / v[3], py = v[1] / v[3];
+        if (!std::isfinite(px) || !std::isfinite(py) || std::fabs(px) > 1e9 || std::fabs(py) > 1e9) return full;
+        if (k == 0 || px < xmin) xmin = px;
+        if (k == 0 || px > xmax) xmax = px;
+        if (k == 0 || py < ymin) ymin = py;
+        if (k == 0 || py > ymax) ymax = py;
+    }
+    PixBox b;
+    b.x0 = (int)std::max(0.0, std::floor(xmin) - 2.0);
+    b.y0 = (int)std::max(0.0, std::floor(ymin) - 2.0);
+    b.x1 = (int)std::min((double)c->W, std::ceil(xmax) + 3.0);
+    b.y1 = (int)std::min((double)c->H, std::ceil(ymax) + 3.0);
+    return b;  // (may be empty: the mesh is off the frame)
+}
+
 int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, const tr_shade_ext* x) {
     if (!c || !mesh || !p) return TR_ERR_INVALID;
     if (mesh->any_uv && (!p->diffuse || (p->use_normal_map && !p->normal_map)))
@@ -1148,6 +1212,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     }
     const uint32_t tri_base = c->tri_total;
     const uint32_t n_halves = 2u * (uint32_t)mesh->n_tris;
+    c->frame_box.add(draw_pix_box(c, mesh, p->pmv));
     {
         ProfScope ps(c, ST_SETUP);
         SetupArgs sa;
@@ -1526,7 +1591,33 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         sa.view_pix = (uint32_t)((size_t)c->W * c->H);
         dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, c->blk_rows_per_view * (unsigned)(views ? c->n_views : 1));
         sa.blk_y0 = 0;
-        if (!views && !shade_trace_on() && out_mask == TR_OUT_RGBA8 && (c->y_lo > 0 || c->y_hi < c->H || c->shaded_lo > 0 || c->shaded_hi < c->H)) {
+        sa.blk_x0 = 0;
+        sa.blocks_x = sgrid.x;
+        bool boxed = false, nothing = false;
+        if (c->shade_box && sa.skip_clean && !views && !shade_trace_on() && !c->frame_has_ext) {
+            // the cheap resolve: a block outside the frame's screen box holds no key, and one outside the box the last
+            // launch may have painted already shows the background -- such blocks (3/4 of the 4K head frame) would
+            // read their two flag bytes and leave; they are not launched at all
+            PixBox cur = c->frame_box;
+            cur.y0 = std::max(cur.y0, c->y_lo);
+            cur.y1 = std::min(cur.y1, c->y_hi);
+            if (cur.empty()) cur = PixBox();
+            PixBox go = cur;
+            go.add(c->paint_box);
+            c->paint_box = cur;
+            boxed = true;
+            if (go.empty()) {
+                nothing = true;
+            } else {
+                sa.blk_x0 = (uint32_t)(go.x0 / kShadeBW);
+                sa.blk_y0 = (uint32_t)(go.y0 / kShadeBH);
+                sgrid.x = (unsigned)((go.x1 + kShadeBW - 1) / kShadeBW) - sa.blk_x0;
+                sgrid.y = (unsigned)((go.y1 + kShadeBH - 1) / kShadeBH) - sa.blk_y0;
+            }
+        } else {
+            c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = c->W; c->paint_box.y1 = c->H;
+        }
+        if (!boxed && !views && !shade_trace_on() && out_mask == TR_OUT_RGBA8 && (c->y_lo > 0 || c->y_hi < c->H || c->shaded_lo > 0 || c->shaded_hi < c->H)) {
             // a band context (RGBA8 only: the other planes are rewritten whole): nothing lands outside [y_lo, y_hi); the
             // rows the previous launch covered are included so that a band that moved (balanced_bands re-cuts between frames) leaves no stale colour behind
             const int lo = c->y_lo < c->shaded_lo ? c->y_lo : c->shaded_lo, hi = c->y_hi > c->shaded_hi ? c->y_hi : c->shaded_hi;
@@ -1572,7 +1663,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
                 TR_HIP(c, hipEventRecord(it->second, c->stream));
             }
         }
-        else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        else if (!nothing) hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }
     if (c->mode != 1 && out_mask == TR_OUT_RGBA8) {

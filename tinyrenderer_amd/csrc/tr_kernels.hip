@@ -1687,7 +1687,9 @@ struct ShadeArgs {
     // batched views (k_shade<false, false, true>): the grid is the views stacked in y; view v owns block rows
     // [v * view_blk_rows, (v + 1) * view_blk_rows), plane pixels from v * view_pix and draw-table entry v
     uint32_t view_blk_rows, view_pix;
-    uint32_t blk_y0;  // first block row of the launch (band contexts; 0 otherwise)
+    uint32_t blk_y0;  // first block row of the launch (band contexts, boxed launches; 0 otherwise)
+    uint32_t blk_x0;  // first block column of the launch (boxed launches)
+    uint32_t blocks_x;  // blocks per row of the FRAME (the launch's gridDim.x may be smaller)
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
@@ -1783,14 +1785,15 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
             t[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
         }
     };
-    const int x = blockIdx.x * kShadeBW + (threadIdx.x & (kShadeBW - 1));
+    const uint32_t bx = blockIdx.x + (VIEWS ? 0u : a.blk_x0);
+    const int x = (int)bx * kShadeBW + (threadIdx.x & (kShadeBW - 1));
     // (a context that owns a band of rows launches the block rows of its band only: blk_y0 is the first of them)
     const uint32_t by = blockIdx.y + (VIEWS ? 0u : a.blk_y0);
     const uint32_t view = VIEWS ? by / a.view_blk_rows : 0u;
     const int y = (int)(by - view * (VIEWS ? a.view_blk_rows : 0u)) * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
     const uint32_t pix = (VIEWS ? view * a.view_pix : 0u) + (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
-    const uint32_t blk = by * gridDim.x + blockIdx.x;
+    const uint32_t blk = by * a.blocks_x + bx;
     if (a.skip_clean) {
         // Nothing landed in this block: its keys are all "none".  If the previous frame left it
         // at the background colour too there is nothing to do; otherwise repaint the background.
