@@ -1371,6 +1371,7 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
     TR_HIP(c, hipEventSynchronize(c->view_ev[turn]));
     ViewDev* stage = c->view_stage[turn];
     for (int v = 0; v < n_views; ++v) {
+        c->frame_box.add(draw_pix_box(c, mesh, params[v].pmv));
         std::memcpy(stage[v].pmv.m, params[v].pmv, sizeof(stage[v].pmv.m));
         std::memcpy(stage[v].nmat.m, params[v].normal_mat, sizeof(stage[v].nmat.m));
         fill_draw_dev(stage[v].draw, &params[v]);
@@ -1594,7 +1595,8 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         sa.blk_x0 = 0;
         sa.blocks_x = sgrid.x;
         bool boxed = false, nothing = false;
-        if (c->shade_box && sa.skip_clean && !views && !shade_trace_on() && !c->frame_has_ext) {
+        sa.launch_rows = c->blk_rows_per_view;
+        if (c->shade_box && sa.skip_clean && !shade_trace_on() && !c->frame_has_ext) {
             // the cheap resolve: a block outside the frame's screen box holds no key, and one outside the box the last
             // launch may have painted already shows the background -- such blocks (3/4 of the 4K head frame) would
             // read their two flag bytes and leave; they are not launched at all
@@ -1613,6 +1615,8 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
                 sa.blk_y0 = (uint32_t)(go.y0 / kShadeBH);
                 sgrid.x = (unsigned)((go.x1 + kShadeBW - 1) / kShadeBW) - sa.blk_x0;
                 sgrid.y = (unsigned)((go.y1 + kShadeBH - 1) / kShadeBH) - sa.blk_y0;
+                sa.launch_rows = sgrid.y;
+                if (views) sgrid.y *= (unsigned)c->n_views;  // (the same box in every slice of the batch)
             }
         } else {
             c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = c->W; c->paint_box.y1 = c->H;
@@ -1629,7 +1633,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         sa.trace = nullptr;
         static const char* shade_trace = std::getenv("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
         if (views) {
-            hipLaunchKernelGGL((k_shade<false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+            if (!nothing) hipLaunchKernelGGL((k_shade<false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         } else if (shade_trace && !c->frame_has_ext) {
             const size_t words = (size_t)sgrid.x * sgrid.y * 4 * 4;
             static unsigned long long* buf = nullptr;

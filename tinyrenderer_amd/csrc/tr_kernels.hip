@@ -1689,6 +1689,7 @@ struct ShadeArgs {
     uint32_t view_blk_rows, view_pix;
     uint32_t blk_y0;  // first block row of the launch (band contexts, boxed launches; 0 otherwise)
     uint32_t blk_x0;  // first block column of the launch (boxed launches)
+    uint32_t launch_rows;  // batched views: block rows per view in this launch
     uint32_t blocks_x;  // blocks per row of the FRAME (the launch's gridDim.x may be smaller)
 };
 
@@ -1785,12 +1786,14 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
             t[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
         }
     };
-    const uint32_t bx = blockIdx.x + (VIEWS ? 0u : a.blk_x0);
+    const uint32_t bx = blockIdx.x + a.blk_x0;
     const int x = (int)bx * kShadeBW + (threadIdx.x & (kShadeBW - 1));
     // (a context that owns a band of rows launches the block rows of its band only: blk_y0 is the first of them)
-    const uint32_t by = blockIdx.y + (VIEWS ? 0u : a.blk_y0);
-    const uint32_t view = VIEWS ? by / a.view_blk_rows : 0u;
-    const int y = (int)(by - view * (VIEWS ? a.view_blk_rows : 0u)) * kShadeBH + (threadIdx.x / kShadeBW);
+    // (a batch of views launches rows [blk_y0, blk_y0 + launch_rows) of every view, one view after the other)
+    const uint32_t view = VIEWS ? blockIdx.y / a.launch_rows : 0u;
+    const uint32_t row = a.blk_y0 + (VIEWS ? blockIdx.y - view * a.launch_rows : blockIdx.y);
+    const uint32_t by = (VIEWS ? view * a.view_blk_rows : 0u) + row;
+    const int y = (int)row * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
     const uint32_t pix = (VIEWS ? view * a.view_pix : 0u) + (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
     const uint32_t blk = by * a.blocks_x + bx;
