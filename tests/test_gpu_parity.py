@@ -886,3 +886,44 @@ def test_boxed_shade_launch_follows_what_moves(oracle):
             assert st.status_flags() == 0
     finally:
         st.close()
+
+
+def test_band_contexts_drop_clusters_exactly(oracle):
+    """Band contexts of a 159 488-triangle mesh drop whole clusters of 64 triangles (k_cull_clusters; the scan and
+    k_build_shade consult the same bytes, the dropped clusters' flags are cleared).  One context, frame after frame:
+    random bands (narrow, wide, one tile row, the whole frame), the big mesh alone and behind a small draw that puts
+    its triangles at a frame position that is no multiple of 64 or 32, the camera moved between frames -- the band's
+    rows must equal the oracle's, in keys, depth and colour."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import MeshComponent, ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 960, 544
+    head = SU.component("head")
+    fine = MeshComponent(scenes.subdivide(head.mesh, 3), head.texture, head.normal_map)
+    eye_mc = SU.component("eye_inner")
+    rng = np.random.default_rng(11)
+    st = ModelRendererState(W, Hh, raster_mode=0)
+    try:
+        for n in range(7):
+            fine.transform.set_rotation((0.025 + 0.4 * n, 0.1 * n, 0.0))
+            eye = (0.5 * np.sin(n), 0.1 * n - 0.3, 2.0 - 0.15 * n)
+            draws = [(fine, scenes.shader_for(fine, W, Hh, eye=eye))]
+            if n % 2:
+                draws = [(eye_mc, scenes.shader_for(eye_mc, W, Hh, eye=eye))] + draws
+            lo = int(rng.integers(0, Hh // 16)) * 16
+            hi = min(Hh, lo + 16 * int(rng.integers(1, 12)))
+            if n == 5:
+                lo, hi = 0, Hh
+            o = SU.oracle_render(oracle, W, Hh, draws)
+            clear_screen(st)
+            st.set_band(lo, hi)
+            for d in draws:
+                render_mesh_component(st, *d)
+            st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z | _ffi.TR_OUT_KEY | _ffi.TR_OUT_RGBA_F64)
+            assert np.array_equal(st.winner_keys()[:, lo:hi], o["key"][:, lo:hi]), (n, lo, hi)
+            assert np.array_equal(st.z_buffer[..., 0][:, lo:hi], o["z"][:, lo:hi], equal_nan=True), (n, lo, hi)
+            assert np.array_equal(st.frame_buffer[:, lo:hi], o["fb"][:, lo:hi]), (n, lo, hi)
+            assert np.array_equal(st.present()[Hh - hi:Hh - lo], o["present"][Hh - hi:Hh - lo]), (n, lo, hi)
+            assert st.status_flags() == 0
+    finally:
+        st.close()
