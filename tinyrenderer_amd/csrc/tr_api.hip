@@ -71,6 +71,8 @@ struct tr_context {
     int shaded_lo = 0, shaded_hi = 0;  // rows the last shade launch covered (a band context shades its band's rows only)
     PixBox frame_box;   // where this frame's draws can land a sample (projected mesh boxes, a margin added); tr_clear empties it
     PixBox paint_box;   // where the colour plane may differ from the background after the last shade launch
+    bool depth_split = true;  // TR_DEPTH_SPLIT: draws that use k_small / k_mid split their triangles at the depth of the mesh box's centre
+    bool split_any = false;   // a draw of this frame did
     bool shade_box = true;  // TR_SHADE_BOX: the cheap resolve launches the blocks of frame_box + paint_box only
     // batched views (tr_create_views / tr_render_views): the planes hold max_views slices of W x H pixels
     int max_views = 1;
@@ -360,6 +362,7 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.live_cap = kChunkLiveCap;
     ra.use_live = 0;
     ra.rec_ready = 0;
+    ra.phase = 0;
     ra.clean_state = nullptr;
     ra.clean_words = 0;
     ra.clean_nan = nullptr;
@@ -556,16 +559,23 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
     if (pass == 0) {
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
         launch_k_raster<0>(c->precheck, dbg, threads, grid, block, c->stream, ra);
-        if (c->small_any) {
-            const dim3 sg(small_grid(h_hi - h_lo));
-            if (c->precheck) hipLaunchKernelGGL((k_small<0, true>), sg, dim3(256), 0, c->stream, ra, c->half_live);
-            else hipLaunchKernelGGL((k_small<0, false>), sg, dim3(256), 0, c->stream, ra, c->half_live);
+        // the sweeps of small / mid triangles in two launches when a draw of the frame split its triangles by depth
+        // (kFlagFar): the near ones lower the plane, most samples of the far ones then fail the plain test
+        const bool two = c->split_any && c->precheck;
+        for (uint32_t ph = two ? 1u : 0u; ph <= (two ? 2u : 0u); ++ph) {
+            ra.phase = ph;
+            if (c->small_any) {
+                const dim3 sg(small_grid(h_hi - h_lo));
+                if (c->precheck) hipLaunchKernelGGL((k_small<0, true>), sg, dim3(256), 0, c->stream, ra, c->half_live);
+                else hipLaunchKernelGGL((k_small<0, false>), sg, dim3(256), 0, c->stream, ra, c->half_live);
+            }
+            if (c->mid_any) {
+                const dim3 mg(mid_grid(h_hi - h_lo));
+                if (c->precheck) hipLaunchKernelGGL((k_mid<0, true>), mg, dim3(64 * kMidWaves), 0, c->stream, ra, c->half_live);
+                else hipLaunchKernelGGL((k_mid<0, false>), mg, dim3(64 * kMidWaves), 0, c->stream, ra, c->half_live);
+            }
         }
-        if (c->mid_any) {
-            const dim3 mg(mid_grid(h_hi - h_lo));
-            if (c->precheck) hipLaunchKernelGGL((k_mid<0, true>), mg, dim3(64 * kMidWaves), 0, c->stream, ra, c->half_live);
-            else hipLaunchKernelGGL((k_mid<0, false>), mg, dim3(64 * kMidWaves), 0, c->stream, ra, c->half_live);
-        }
+        ra.phase = 0;
         if (h_hi / 2u > c->counted_upto) c->counted_upto = h_hi / 2u;
     } else {
         if (c->small_any)  // (before k_raster<1>, whose tail zeroes the other half of the per-frame state)
@@ -731,6 +741,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     c->shaded_lo = 0;
     c->shaded_hi = height;
     c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = width; c->paint_box.y1 = height;
+    if (const char* e = std::getenv("TR_DEPTH_SPLIT")) c->depth_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SHADE_BOX")) c->shade_box = std::atoi(e) != 0;
     c->max_views = max_views;
     c->n_views = max_views;  // (an empty frame resolves every slice)
@@ -920,6 +931,7 @@ int tr_clear(tr_context* c) {
         TR_HIP(c, hipMemsetAsync(c->small_grp, 0, c->tri_cap / 32 + 1, c->stream));
     c->small_any = false;
     c->mid_any = false;
+    c->split_any = false;
     c->view_tris = 0;
     c->n_views = c->max_views;  // (an empty frame resolves every slice)
     return TR_OK;
@@ -1132,6 +1144,21 @@ static PixBox draw_pix_box(const tr_context* c, const tr_mesh* mesh, const doubl
     return b;  // (may be empty: the mesh is off the frame)
 }
 
+// Viewport depth of the mesh box's centre under `pmv` (NaN: none): k_setup marks the triangles behind it kTriFar.
+static double split_depth(const tr_context* c, const tr_mesh* mesh, const double pmv[16]) {
+    if (!mesh->box_ok) return std::nan("");
+    const double q[3] = {0.5 * (mesh->box[0] + mesh->box[3]), 0.5 * (mesh->box[1] + mesh->box[4]), 0.5 * (mesh->box[2] + mesh->box[5])};
+    double g[4];
+    for (int r = 0; r < 4; ++r) g[r] = pmv[r] * q[0] + pmv[4 + r] * q[1] + pmv[8 + r] * q[2] + pmv[12 + r];
+    if (!(g[3] > 1e-9)) return std::nan("");
+    const Mat4 vpm = viewport_matrix(c->W, c->H);
+    const double n[3] = {g[0] / g[3], g[1] / g[3], g[2] / g[3]};
+    const double vz = vpm.m[2] * n[0] + vpm.m[6] * n[1] + vpm.m[10] * n[2] + vpm.m[14];
+    const double vw = vpm.m[3] * n[0] + vpm.m[7] * n[1] + vpm.m[11] * n[2] + vpm.m[15];
+    const double z = vz / vw;
+    return std::isfinite(z) ? z : std::nan("");
+}
+
 int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, const tr_shade_ext* x) {
     if (!c || !mesh || !p) return TR_ERR_INVALID;
     if (mesh->any_uv && (!p->diffuse || (p->use_normal_map && !p->normal_map)))
@@ -1240,6 +1267,11 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         if (defer) sa.mode |= 8;  // no TriShade now: k_build_shade writes it for the triangles the winner pass flags
         sa.per_corner = defer ? 1 : 0;
         sa.bounds = mesh->bounds;
+        sa.z_split = std::nan("");
+        if (c->depth_split && (sa.mode & (4 | 16))) {
+            sa.z_split = split_depth(c, mesh, p->pmv);
+            if (sa.z_split == sa.z_split) c->split_any = true;
+        }
         sa.cull = nullptr;
         if (defer && mesh->bounds && (c->y_lo > 0 || c->y_hi < c->H)) {
             // a band context: whole clusters of the mesh that miss its rows are dropped before anything of theirs is read
@@ -1375,7 +1407,7 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
         std::memcpy(stage[v].pmv.m, params[v].pmv, sizeof(stage[v].pmv.m));
         std::memcpy(stage[v].nmat.m, params[v].normal_mat, sizeof(stage[v].nmat.m));
         fill_draw_dev(stage[v].draw, &params[v]);
-        stage[v].pad[0] = stage[v].pad[1] = 0;
+        stage[v].z_split = c->depth_split ? split_depth(c, mesh, params[v].pmv) : std::nan("");
     }
     TR_HIP(c, hipMemcpyAsync(c->view_table, stage, (size_t)n_views * sizeof(ViewDev), hipMemcpyHostToDevice, c->stream));
     TR_HIP(c, hipEventRecord(c->view_ev[turn], c->stream));
@@ -1406,6 +1438,7 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
         sa.draw_table = c->draw_table;
         sa.half_off = c->half_off;
         sa.views = c->view_table; sa.n_views = (uint32_t)n_views;
+        if (c->depth_split && (sa.mode & (4 | 16))) c->split_any = true;
         hipLaunchKernelGGL((k_setup<false, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
         rc = launch_scan(c, 0u, n_halves);

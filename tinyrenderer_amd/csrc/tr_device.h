@@ -39,6 +39,10 @@ struct __attribute__((aligned(128))) TriRaster {
 };
 constexpr uint32_t kTriNonFinite = 1u;
 constexpr uint32_t kTriSmall = 2u;     // both halves have at most small_res + 1 scanlines (kSmallRes by default): rastered by k_small, owns no slots
+constexpr uint32_t kTriFar = 4u;       // its centroid lies behind the draw's split depth (z_split): k_small / k_mid take such
+                                       // triangles in a second depth launch, after the nearer ones have lowered the plane
+// per-triangle flag byte of the k_small / k_mid sweeps (small_flag): path in the low bits, kFlagFar on top
+constexpr uint8_t kFlagSmall = 1, kFlagMid = 2, kFlagPath = 3, kFlagFar = 4;
 constexpr uint32_t kSmallRes = 8u;
 constexpr int kTile = 16;             // screen tile edge in pixels
 constexpr double kPruneMargin = 1.0 / 64.0;  // slack (pixels) of every conservative range test
@@ -74,7 +78,7 @@ struct __attribute__((aligned(128))) ViewDev {
     Mat4 pmv;      // perspective * model_view
     Mat4 nmat;     // (model_view^T)^-1
     DrawDev draw;
-    uint32_t pad[2];
+    double z_split;  // viewport z of the mesh box's centre under this view, or NaN (kTriFar)
 };
 static_assert(sizeof(ViewDev) == 384, "ViewDev must be 384 B");
 

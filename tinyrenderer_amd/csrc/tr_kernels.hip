@@ -84,6 +84,7 @@ struct SetupArgs {
     int per_corner;        // k_setup<false, false>: evaluate the vertex stage per corner instead of reading ndc / nout
     const double* bounds;  // per 64 consecutive triangles of the mesh: min xyz, max xyz of their positions (k_mesh_bounds),
                            // or nullptr; a context that owns a band drops whole clusters that project outside its rows
+    double z_split;        // viewport z of the mesh box's centre, or NaN: triangles whose centroid is farther get kTriFar
     uint8_t* cull;         // per cluster of this draw: 1 = misses the band (written by k_cull_clusters), or nullptr
 };
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, 
                                               uint32_t* flags);
 
 __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1,
-                                               const Mat4& pmv, const Mat4& nmat, uint32_t draw, uint32_t seq);
+                                               const Mat4& pmv, const Mat4& nmat, uint32_t draw, uint32_t seq, double z_split);
 
 // FUSED = false: vertex stage read from k_transform's arrays, prefix by the k_scan_* kernels.
 // FUSED = true (draws of up to 256 workgroups of 64 to 256 threads): one launch does transform + setup + scan.
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
         const ViewDev& vd = a.views[view];
         if (kv == 0) a.draw_table[a.draw + view] = vd.draw;
         uint32_t c0 = 0, c1 = 0;
-        setup_triangle(a, kv, true, c0, c1, vd.pmv, vd.nmat, a.draw + view, a.tri_base + g);
+        setup_triangle(a, kv, true, c0, c1, vd.pmv, vd.nmat, a.draw + view, a.tri_base + g, vd.z_split);
         a.half_cnt[2 * (size_t)(a.tri_base + g)] = c0;  // (setup_triangle leaves the counts to its caller when `fused`)
         a.half_cnt[2 * (size_t)(a.tri_base + g) + 1] = c1;
         return;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     if (k < a.n_tris) {
         // (per_corner: a draw whose shade records are deferred needs no normals here and its positions once per
         // corner: the vertex stage is evaluated in place, there is no k_transform launch and no ndc array)
-        setup_triangle(a, k, FUSED || a.per_corner, c0, c1, a.pmv, a.nmat, a.draw, a.tri_base + (uint32_t)k);
+        setup_triangle(a, k, FUSED || a.per_corner, c0, c1, a.pmv, a.nmat, a.draw, a.tri_base + (uint32_t)k, a.z_split);
         if (!FUSED && a.per_corner && (a.mode & 1)) {  // (setup_triangle leaves the counts to its caller when `fused`)
             a.half_cnt[2 * (size_t)(a.tri_base + (uint32_t)k)] = c0;
             a.half_cnt[2 * (size_t)(a.tri_base + (uint32_t)k) + 1] = c1;
@@ -322,7 +323,7 @@ __device__ __forceinline__ TriShade make_shade_record(const SetupArgs& a, const 
 }
 
 __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool fused, uint32_t& cnt0, uint32_t& cnt1,
-                                               const Mat4& pmv, const Mat4& nmat, uint32_t draw, uint32_t seq) {
+                                               const Mat4& pmv, const Mat4& nmat, uint32_t draw, uint32_t seq, double z_split) {
     const uint32_t* ix = a.idx + 9 * (size_t)k;
     uint32_t iv[3] = {ix[0], ix[3], ix[6]};
     uint32_t it[3] = {ix[1], ix[4], ix[7]};
@@ -353,7 +354,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         cull = cull && out;
     }
     TriRaster R;
-    bool small = false, mid = false;
+    bool small = false, mid = false, far = false;
     R.res[0] = R.res[1] = 0;
     R.tx0 = 1; R.tx1 = 0; R.ty0 = 1; R.ty1 = 0; R.flags = 0; R.slot_shift = 0;
     R.pad[0] = R.pad[1] = 0;
@@ -478,6 +479,9 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
                 }
             }
         }
+        // (depth = -z: farther = smaller z.  NaN on either side: not far.)
+        far = (R.s0[2] + R.s1[2]) + R.s2[2] < 3.0 * z_split;
+        if (far) R.flags |= kTriFar;
         // A triangle of a few pixels (a few scanlines of a few samples each) is cheaper as ONE thread
         // per half that walks its samples than as slots of the frame-wide sequence: k_small takes it,
         // and it owns no slots.  (mode bit 2: the draw uses that path.)
@@ -510,7 +514,8 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         }
         }  // !out_of_band
     }
-    if (a.small_flag) a.small_flag[seq] = mid ? 2 : (small ? 1 : 0);  // (every draw writes it: k_small / k_mid may sweep draws that do not use them)
+    if (a.small_flag)  // (every draw writes it: k_small / k_mid may sweep draws that do not use them)
+        a.small_flag[seq] = (uint8_t)((mid ? kFlagMid : (small ? kFlagSmall : 0)) | (far && small ? kFlagFar : 0));
     if (small && !mid) a.small_grp[seq >> 5] = 1;  // (zeroed by tr_clear; lanes of a group store the same byte)
     // deferred shade record: a triangle with slots (or of k_mid) always gets one (those kernels keep no per-triangle
     // state); one of a few pixels (k_small, the bulk of a high-polygon mesh) only if the winner pass flags it
@@ -896,6 +901,7 @@ struct RasterArgs {
     // batched views (tr_render_views): triangle t belongs to view t / view_tris, whose planes start view_pix
     // pixels and whose shade blocks start view_blk blocks after the previous view's; 0 = one view
     uint32_t view_tris, view_pix, view_blk;
+    uint32_t phase;             // k_small / k_mid depth pass: 0 every triangle, 1 the near ones only, 2 the far ones (kFlagFar) only
     uint32_t mid_shift;         // k_mid: log2 of the halves a wave looks up at once (0 .. 6)
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
     unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
@@ -1370,7 +1376,13 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
         const uint32_t u = u0 + turn * n_waves;
         const uint32_t h = u * 64u + lane;
         if (h < a.h_lo || h >= a.h_hi) continue;
-        if (a.small_flag[h >> 1] != 1) continue;  // (a byte per triangle: the other triangles' records are not touched)
+        {   // (a byte per triangle: the other triangles' records are not touched)
+            const uint32_t f = a.small_flag[h >> 1];
+            if ((f & kFlagPath) != kFlagSmall) continue;
+            // near triangles first, the far ones in a second launch: most of their samples then fail the plain test
+            // against the plane instead of lowering it with an atomic that a nearer sample lowers again
+            if (PASS == 0 && a.phase && ((f & kFlagFar) ? 2u : 1u) != a.phase) continue;
+        }
         if (PASS == 1 && a.use_live && !nan_active && half_live[h] == 0) continue;
         const uint32_t tri = h >> 1, half = h & 1u;
         const TriRaster& t = a.rast[tri];
@@ -1517,7 +1529,8 @@ __global__ __launch_bounds__(64 * kMidWaves) void k_mid(RasterArgs a, uint8_t* h
       bool mine = false;
       if (lane < bn) {
           const uint32_t hl = blk * bn + lane;
-          mine = hl >= a.h_lo && hl < a.h_hi && a.small_flag[hl >> 1] == 2;
+          const uint32_t f = hl >= a.h_lo && hl < a.h_hi ? a.small_flag[hl >> 1] : 0u;
+          mine = (f & kFlagPath) == kFlagMid && !(PASS == 0 && a.phase && ((f & kFlagFar) ? 2u : 1u) != a.phase);
           if (mine && PASS == 1 && a.use_live && !nan_active) mine = half_live[hl] != 0;
       }
       unsigned long long todo = __ballot(mine);
