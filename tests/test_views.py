@@ -176,3 +176,25 @@ def test_views_context_refusals():
             render_views(plain, mc, [scenes.shader_for(mc, 64, 48)])
     finally:
         plain.close()
+
+
+def test_cheap_resolve_of_batches_of_changing_size_and_place(oracle):
+    """The RGBA8-only resolve of a batch launches the union of the views' screen boxes (plus what earlier launches
+    painted) in the slices of THIS batch only: a full batch, a short one somewhere else, a full one in a third place --
+    every slice the last batch owns must show its view and nothing of the first batch's."""
+    W, H = 320, 200
+    mc = SU.component("eye_inner")
+    mc.parent = None
+    st = ModelRendererState(W, H, max_views=6)
+    try:
+        def shaders(n, dx, dist):
+            return [scenes.shader_for(mc, W, H, eye=(dx + 0.05 * k, 0.1 * k - 0.2, dist)) for k in range(n)]
+
+        for sh in (shaders(6, -0.9, 1.0), shaders(2, 0.9, 1.4), shaders(6, 0.3, 2.5)):
+            render_views(st, mc, sh, _ffi.TR_OUT_RGBA8)
+            for v, s_ in enumerate(sh):
+                st.select_view(v)
+                want = SU.oracle_render(oracle, W, H, [(mc, s_)])["present"]
+                assert np.array_equal(st.present(), want), v
+    finally:
+        st.close()

@@ -1639,7 +1639,10 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             if (cur.empty()) cur = PixBox();
             PixBox go = cur;
             go.add(c->paint_box);
-            c->paint_box = cur;
+            // (a batch of fewer views than the context has slices leaves the other slices as they were: what they
+            // may show stays in the box until a launch covers every slice again)
+            if (views && c->n_views < c->max_views) c->paint_box.add(cur);
+            else c->paint_box = cur;
             boxed = true;
             if (go.empty()) {
                 nothing = true;
