@@ -1651,6 +1651,14 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
                 sa.blk_y0 = (uint32_t)(go.y0 / kShadeBH);
                 sgrid.x = (unsigned)((go.x1 + kShadeBW - 1) / kShadeBW) - sa.blk_x0;
                 sgrid.y = (unsigned)((go.y1 + kShadeBH - 1) / kShadeBH) - sa.blk_y0;
+                // (workgroups go to the eight XCDs in turn by their linear index: with a row of a multiple of 8 blocks --
+                // or of any even number, in part -- a block COLUMN always lands on the same XCD, and the columns an object
+                // covers then load the XCDs unevenly: shade launches of a 32-block-wide box took up to 2.5x as long as
+                // full-frame ones beside other streams' kernels.  An odd row length walks every column round the XCDs.)
+                if ((sgrid.x & 1u) == 0) {
+                    if (sa.blk_x0 + sgrid.x < sa.blocks_x) sgrid.x += 1;
+                    else if (sa.blk_x0 > 0) { sa.blk_x0 -= 1; sgrid.x += 1; }
+                }
                 sa.launch_rows = sgrid.y;
                 if (views) sgrid.y *= (unsigned)c->n_views;  // (the same box in every slice of the batch)
             }
