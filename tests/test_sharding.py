@@ -63,10 +63,15 @@ def _worker(rank, world, port, n_views, W, H, out_path):
         y_lo, y_hi = sharding.band_rows(H, rank, world)
         band = torch.from_numpy(_render_view(0, n_views, W, H)[y_lo:y_hi].copy())
         full = sharding.gather_bands(band, H, dst=0)
+        # bands of unequal height (what balanced_bands gives), one of them empty when there are more than two ranks
+        cuts = [0, 16] + [H] * (world - 1)
+        spans = list(zip(cuts[:-1], cuts[1:]))
+        a_lo, a_hi = spans[rank]
+        uneven = sharding.gather_bands(torch.from_numpy(_render_view(0, n_views, W, H)[a_lo:a_hi].copy()), H, dst=0, spans=spans)
         if rank == 0:
-            np.savez(out_path, frames=frames.numpy(), full=full.numpy())
+            np.savez(out_path, frames=frames.numpy(), full=full.numpy(), uneven=uneven.numpy())
         else:
-            assert frames is None and full is None
+            assert frames is None and full is None and uneven is None
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +85,7 @@ def test_world2_gloo_views_and_bands(tmp_path):
     want = np.stack([_render_view(k, n_views, W, H) for k in range(n_views)])
     assert np.array_equal(got["frames"], want)
     assert np.array_equal(got["full"], want[0])
+    assert np.array_equal(got["uneven"], want[0])
     assert (want != np.int32(-16777216)).any()  # something other than the clear colour was drawn
 
 

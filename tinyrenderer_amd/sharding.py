@@ -150,18 +150,27 @@ def gather_frames(local, n_total, dst=0):
 def gather_bands(local_band, height, dst=0, tile=TILE, spans=None):
     """Gather per-rank bands (rows [y_lo, y_hi) of one frame, shape (rows, W[, C])) onto `dst`
     and stack them into the (height, W[, C]) frame.  `spans`: the bands of all ranks if they are
-    not the equal ones of band_rows (balanced_bands)."""
+    not the equal ones of band_rows (balanced_bands).
+    Point-to-point: every rank sends exactly its rows and `dst` receives each band straight into its place in the
+    frame -- balanced bands differ in height several times over (8 bands of the 10^7-triangle head: 224 to 1 200
+    rows), and a `dist.gather` of bands padded to the tallest moved 2.2x the frame and copied it once more."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world == 1:
         return local_band
-    local_band = _stage(local_band)
+    local_band = _stage(local_band).contiguous()
     spans = [band_rows(height, r, world, tile) for r in range(world)] if spans is None else list(spans)
-    max_rows = max(hi - lo for lo, hi in spans)
-    pad = torch.zeros((max_rows,) + tuple(local_band.shape[1:]), dtype=local_band.dtype, device=local_band.device)
-    pad[: local_band.shape[0]] = local_band
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
+    lo, hi = spans[rank]
+    assert local_band.shape[0] == hi - lo, (tuple(local_band.shape), spans[rank])
     if rank != dst:
+        if hi > lo:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_band, dst)]):
+                req.wait()
         return None
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(spans)], dim=0)
+    full = torch.empty((height,) + tuple(local_band.shape[1:]), dtype=local_band.dtype, device=local_band.device)
+    full[lo:hi] = local_band
+    ops = [dist.P2POp(dist.irecv, full[a:b], r) for r, (a, b) in enumerate(spans) if r != dst and b > a]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return full
