@@ -397,20 +397,37 @@ def main():
         out["cpu_baseline"] = cpu_baseline(W, H, draws)
     for s_ in states:
         s_.close()
-    # ---- the other two multi-GPU configurations of BASELINE.json, beside the headline (never part of `value`)
-    if not args.no_secondary:
-        out["secondary"] = {}
-        for name, fn in (("bands_8k_10M_triangles", secondary_bands), ("orbit_4096_views_1080p", secondary_orbit)):
-            try:
-                out["secondary"][name] = fn(torch, dist, rank, world, local_rank)
-            except Exception as e:  # (a failure here must not cost the headline line)
-                out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         v = torch.tensor([0 if verified is False else 1], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         if verified is not None:
             verified = bool(v.item())
             out["verified"] = verified
+    # ---- the other two multi-GPU configurations of BASELINE.json, beside the headline (never part of `value`)
+    if not args.no_secondary:
+        # A failure here must not cost the headline line, and neither may a hang (these records run collectives this
+        # container cannot rehearse on more than one GPU): past the limit rank 0 prints the line without them and
+        # every rank leaves.
+        import threading
+
+        out["secondary"] = {}
+        limit = float(os.environ.get("TR_BENCH_SECONDARY_LIMIT_S", "240"))
+
+        def give_up():
+            if rank == 0:
+                out["secondary"].setdefault("error", f"not finished after {limit:.0f} s")
+                print(json.dumps(out), flush=True)
+            os._exit(3 if verified is False else 0)
+
+        watchdog = threading.Timer(limit + (0.0 if rank == 0 else 10.0), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        for name, fn in (("bands_8k_10M_triangles", secondary_bands), ("orbit_4096_views_1080p", secondary_orbit)):
+            try:
+                out["secondary"][name] = fn(torch, dist, rank, world, local_rank)
+            except Exception as e:
+                out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"}
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
