@@ -1407,6 +1407,11 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                 const unsigned long long cur = PRECHECK ? __hip_atomic_load(&a.depth[pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
                 if (!PRECHECK || ee <= cur) live = true;
                 if (!PRECHECK || ee < cur) atomicMin(&a.depth[pp], ee);
+#ifdef TR_COUNT_ACT  // (diagnostic: "fragments" = lanes that issue an atomic, "samples" = wave-instructions that do)
+                const unsigned long long m = __ballot(!PRECHECK || ee < cur);
+                cnt_inb += (!PRECHECK || ee < cur) ? 1 : 0;
+                cnt_samples += (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) ? 1 : 0;
+#endif
             }
         };
         for (uint32_t i = 0; i <= res; ++i) {
@@ -1421,10 +1426,12 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
                 const int ix = pixel_coord(x, a.W);
                 const int iy = pixel_coord(y, a.H);
                 const bool inb = ix >= 0 && iy >= a.y_lo && iy < a.y_hi;
+#ifndef TR_COUNT_ACT
                 if (PASS == 0 && counted) {
                     cnt_samples += 1;
                     cnt_inb += inb ? 1 : 0;
                 }
+#endif
                 if (!inb) continue;
                 const double dist = -z;
                 const uint32_t pix = pix_base + (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
