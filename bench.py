@@ -138,7 +138,7 @@ def secondary_orbit(torch, dist, rank, world, device, n_total=4096):
     from tinyrenderer_amd.model_renderer import ModelRendererState, make_draw_params
 
     W, H = 1920, 1080
-    batch = int(os.environ.get("TR_BENCH_ORBIT_BATCH", "16"))
+    batch = int(os.environ.get("TR_BENCH_ORBIT_BATCH", "32"))  # (measured on one GPU, 4 contexts: 8 -> 31.0 k, 16 -> 33.2 k, 24 -> 34.4 k, 32 -> 34.9 k views/s)
     n_ctx = int(os.environ.get("TR_BENCH_ORBIT_CONTEXTS", "4"))
     n_total = int(os.environ.get("TR_BENCH_ORBIT_VIEWS", str(n_total)))
     mc = SU.component("diablo")
