@@ -927,3 +927,36 @@ def test_band_contexts_drop_clusters_exactly(oracle):
             assert st.status_flags() == 0
     finally:
         st.close()
+
+
+def test_tiled_planes_frame_with_every_raster_kernel(oracle):
+    """A frame whose FIRST draw is a mesh of small triangles keeps its depth / key planes in tiles of 4 x 2 pixels
+    (plane_index): the draws after it -- an ordinary mesh through k_raster, a degenerate triangle whose NaN depth goes
+    through the side table -- address the same tiled planes, and the cheap and the full resolve read them back."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader, MeshComponent, ModelRendererState, clear_screen, render_mesh_component
+
+    W, Hh = 960, 544
+    head = SU.component("head")
+    fine = MeshComponent(scenes.subdivide(head.mesh, 3), head.texture, head.normal_map)
+    fine.transform.set_rotation((0.3, 0.1, 0.0))
+    eye_mc = SU.component("eye_inner")
+    N = H.NONE_INDEX
+    degenerate = H.Object([[-0.5, 0.25, 0.0], [0.5, 0.25, 0.0], [0.0, 0.25, 0.0]],
+                          [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)), [[0, 0, N, 1, 1, N, 2, 2, N]])
+    deg = _synthetic_component(degenerate)
+    draws = [(fine, scenes.shader_for(fine, W, Hh)), (eye_mc, scenes.shader_for(eye_mc, W, Hh, eye=(0.4, 0.2, 1.1))),
+             (deg, BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0)))]
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    g = SU.gpu_render(W, Hh, draws, mode=0)
+    info = SU.assert_parity(o, g)
+    assert info["f64_colour_mismatches"] == 0
+    st = ModelRendererState(W, Hh, raster_mode=0)  # the cheap resolve, twice (the planes clean themselves in between)
+    try:
+        for _ in range(2):
+            clear_screen(st)
+            for d in draws:
+                render_mesh_component(st, *d)
+            assert np.array_equal(st.present(), o["present"])
+    finally:
+        st.close()

@@ -73,6 +73,8 @@ struct tr_context {
     PixBox paint_box;   // where the colour plane may differ from the background after the last shade launch
     bool depth_split = true;  // TR_DEPTH_SPLIT: draws that use k_small / k_mid split their triangles at the depth of the mesh box's centre
     bool split_any = false;   // a draw of this frame did
+    bool plane_tiles = true;   // TR_PLANE_TILES: frames whose first draw uses k_small keep their planes in 4 x 2 tiles
+    bool frame_tiled = false;  // this frame does
     bool shade_box = true;  // TR_SHADE_BOX: the cheap resolve launches the blocks of frame_box + paint_box only
     // batched views (tr_create_views / tr_render_views): the planes hold max_views slices of W x H pixels
     int max_views = 1;
@@ -363,6 +365,7 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.use_live = 0;
     ra.rec_ready = 0;
     ra.phase = 0;
+    ra.tiled = c->frame_tiled ? 1u : 0u;
     ra.clean_state = nullptr;
     ra.clean_words = 0;
     ra.clean_nan = nullptr;
@@ -742,6 +745,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     c->shaded_hi = height;
     c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = width; c->paint_box.y1 = height;
     if (const char* e = std::getenv("TR_DEPTH_SPLIT")) c->depth_split = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_PLANE_TILES")) c->plane_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SHADE_BOX")) c->shade_box = std::atoi(e) != 0;
     c->max_views = max_views;
     c->n_views = max_views;  // (an empty frame resolves every slice)
@@ -932,6 +936,7 @@ int tr_clear(tr_context* c) {
     c->small_any = false;
     c->mid_any = false;
     c->split_any = false;
+    c->frame_tiled = false;
     c->view_tris = 0;
     c->n_views = c->max_views;  // (an empty frame resolves every slice)
     return TR_OK;
@@ -1258,6 +1263,10 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
             sa.small_res = c->small_res;
             c->small_any = true;
         }
+        // the layout of the depth / key planes is settled by the frame's first draw (every pass of the frame shares it):
+        // tiles of 4 x 2 pixels when that draw is a mesh of small triangles (plane_index, tr_device.h)
+        if (tri_base == 0 && c->draw_count == 0)
+            c->frame_tiled = c->plane_tiles && (sa.mode & 4) && (c->W & 3) == 0 && (c->H & 1) == 0;
         sa.mid_samples = c->mid_samples;
         if (use_mid_path(c, (uint64_t)mesh->n_tris, (uint64_t)mesh->n_tris)) {
             sa.mode |= 16;  // triangles of up to 64 scanlines per half and a few hundred samples: one wave per half (k_mid)
@@ -1629,6 +1638,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         sa.blocks_x = sgrid.x;
         bool boxed = false, nothing = false;
         sa.launch_rows = c->blk_rows_per_view;
+        sa.tiled = c->frame_tiled ? 1u : 0u;
         if (c->shade_box && sa.skip_clean && !shade_trace_on() && !c->frame_has_ext) {
             // the cheap resolve: a block outside the frame's screen box holds no key, and one outside the box the last
             // launch may have painted already shows the background -- such blocks (3/4 of the 4K head frame) would

@@ -150,6 +150,14 @@ __device__ __forceinline__ uint64_t encode_depth(double d) {
     return b ^ ((uint64_t)((int64_t)b >> 63) | 0x8000000000000000ull);
 }
 
+// Index of pixel (ix, iy) in the depth and winner-key planes.  Row-major by default: a scanline's samples are
+// neighbours in memory.  `tiled` (frames of small-triangle meshes, W a multiple of 4 and H of 2): 4 x 2 pixels to a
+// 64-byte segment, the unit of a memory-side atomic request -- the 32 triangles of a k_small wave cover a patch of a
+// few pixels square, every row of which is a segment of its own in the row-major plane.
+__device__ __forceinline__ uint32_t plane_index(uint32_t ix, uint32_t iy, uint32_t W, bool tiled) {
+    return tiled ? ((((iy >> 1) * (W >> 2) + (ix >> 2)) << 3) | ((iy & 1u) << 2) | (ix & 3u)) : iy * W + ix;
+}
+
 // Rust `v.ceil() as i64` followed by `.max(2)` for v >= 0 or NaN; values above `limit`
 // are reported as limit+1 so the caller can flag them.
 __device__ __forceinline__ uint32_t res_from_extent(double m, uint32_t limit) {

@@ -901,6 +901,7 @@ struct RasterArgs {
     // batched views (tr_render_views): triangle t belongs to view t / view_tris, whose planes start view_pix
     // pixels and whose shade blocks start view_blk blocks after the previous view's; 0 = one view
     uint32_t view_tris, view_pix, view_blk;
+    uint32_t tiled;             // the planes' layout this frame: 0 row-major, 1 tiles of 4 x 2 pixels (plane_index)
     uint32_t phase;             // k_small / k_mid depth pass: 0 every triangle, 1 the near ones only, 2 the far ones (kFlagFar) only
     uint32_t mid_shift;         // k_mid: log2 of the halves a wave looks up at once (0 .. 6)
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                     }
                     if (inb) {
                         const double dist = -z;
-                        pix[u] = (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+                        pix[u] = plane_index((uint32_t)ix, (uint32_t)iy, (uint32_t)a.W, a.tiled != 0);
                         meta[u] = (sidx << 18) | j;
                         if (PASS == 1) blk[u] = (uint32_t)(iy / kShadeBH) * (uint32_t)a.blocks_x + (uint32_t)(ix / kShadeBW);
                         if (VIEWS) {
@@ -1434,7 +1435,7 @@ __global__ __launch_bounds__(256) void k_small(RasterArgs a, uint8_t* half_live)
 #endif
                 if (!inb) continue;
                 const double dist = -z;
-                const uint32_t pix = pix_base + (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+                const uint32_t pix = pix_base + plane_index((uint32_t)ix, (uint32_t)iy, (uint32_t)a.W, a.tiled != 0);
                 const unsigned long long key = ((unsigned long long)tri << kKeyTriShift) | ((unsigned long long)half << kKeyHalfShift) |
                                                ((unsigned long long)i << kKeyIShift) | (unsigned long long)j;
                 if (dist != dist) {  // NaN depth: the side table, as in k_raster
@@ -1597,7 +1598,7 @@ __global__ __launch_bounds__(64 * kMidWaves) void k_mid(RasterArgs a, uint8_t* h
             if (PASS == 0 && counted) cnt_inb += inb ? 1 : 0;
             if (!inb) continue;
             const double dist = -z;
-            const uint32_t pix = pix_base + (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+            const uint32_t pix = pix_base + plane_index((uint32_t)ix, (uint32_t)iy, (uint32_t)a.W, a.tiled != 0);
             const unsigned long long key = ((unsigned long long)tri << kKeyTriShift) | ((unsigned long long)half << kKeyHalfShift) |
                                            ((unsigned long long)sidx << kKeyIShift) | (unsigned long long)j;
             if (dist != dist) {  // NaN depth: the side table, as in k_raster
@@ -1714,6 +1715,7 @@ struct ShadeArgs {
     uint32_t blk_y0;  // first block row of the launch (band contexts, boxed launches; 0 otherwise)
     uint32_t blk_x0;  // first block column of the launch (boxed launches)
     uint32_t launch_rows;  // batched views: block rows per view in this launch
+    uint32_t tiled;        // layout of wkey / depth this frame (plane_index)
     uint32_t blocks_x;  // blocks per row of the FRAME (the launch's gridDim.x may be smaller)
 };
 
@@ -1820,6 +1822,8 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     const int y = (int)row * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
     const uint32_t pix = (VIEWS ? view * a.view_pix : 0u) + (uint32_t)y * (uint32_t)a.W + (uint32_t)x;
+    // (the depth / key planes may be tiled this frame; the output planes never are)
+    const uint32_t ppix = (VIEWS ? view * a.view_pix : 0u) + plane_index((uint32_t)x, (uint32_t)y, (uint32_t)a.W, a.tiled != 0);
     const uint32_t blk = by * a.blocks_x + bx;
     if (a.skip_clean) {
         // Nothing landed in this block: its keys are all "none".  If the previous frame left it
@@ -1847,14 +1851,14 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         int tile = (y / kTile) * a.tiles_x + (x / kTile);
         listed = a.tile_off[tile + 1] > a.tile_off[tile];
     }
-    unsigned long long key = listed ? a.wkey[pix] : kKeyNone;
+    unsigned long long key = listed ? a.wkey[ppix] : kKeyNone;
     if (a.self_clean && key != kKeyNone) {  // leave the planes cleared for the next frame
-        a.wkey[pix] = kKeyNone;
-        if (a.depth) a.depth[pix] = kKeyNone;
+        a.wkey[ppix] = kKeyNone;
+        if (a.depth) a.depth[ppix] = kKeyNone;
     }
     if (a.nan && live && a.nan->pix[0] != kNanEmpty) {
         for (uint32_t s = 0; s < kNanSlots; ++s)
-            if (a.nan->pix[s] == pix && a.nan->first_nan[s] < a.nan->first_any[s]) key = a.nan->first_nan[s];
+            if (a.nan->pix[s] == ppix && a.nan->first_nan[s] < a.nan->first_any[s]) key = a.nan->first_nan[s];
     }
     bool has = key != kKeyNone;
     unsigned long long nwin = __popcll(__ballot(has));
