@@ -174,6 +174,8 @@ struct tr_context {
     // tile raster (mode 1)
     int mode = 0;                   // 0 = global-atomic raster (default: faster on MI355X so far), 1 = binned LDS tile raster
     int tiles_x = 0, tiles_y = 0;
+    int tile_w = 16, tile_h = 16;   // TR_TILE=WxH: 16x16, 32x16, 32x32 or 64x32 (k_tile_raster<TW, TH>)
+    int tw_shift = 4, th_shift = 4;
     uint32_t* tile_cnt = nullptr;   // triangles per tile / fill cursor
     uint32_t* tile_off = nullptr;   // n_tiles_padded + 4: offsets, total, number of non-empty tiles
     uint32_t* tile_list = nullptr;  // ids of non-empty tiles
@@ -338,6 +340,16 @@ constexpr uint32_t kChunkLiveCap = 1u << 20;  // 64 M slots per frame get dead-c
 // (a wave per block of 1 << shift halves: single halves while there are fewer than a million, so that a batch of
 // views fills the GPU; blocks of 16 for the meshes of millions of triangles, few of which are of this path)
 uint32_t mid_shift_for(uint32_t n_halves) { return n_halves >= (4u << 20) ? 4u : (n_halves >= (1u << 20) ? 2u : 0u); }
+
+// Tile raster: the instantiation for the context's tile size, and its dynamic LDS (the four waves' private depth + key planes).
+using TileKernel = void (*)(TileArgs);
+TileKernel tile_kernel(const tr_context* c) {
+    if (c->tile_w == 64) return k_tile_raster<64, 32>;
+    if (c->tile_w == 32 && c->tile_h == 32) return k_tile_raster<32, 32>;
+    if (c->tile_w == 32) return k_tile_raster<32, 16>;
+    return k_tile_raster<16, 16>;
+}
+size_t tile_lds_bytes(const tr_context* c) { return (size_t)kTileWaves * c->tile_w * c->tile_h * 2 * sizeof(unsigned long long); }
 
 void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_hi) {
     ra.half_off = c->half_off;
@@ -808,8 +820,18 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (hipMalloc(&c->state_both, 2 * (size_t)kStateWords * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMalloc(&c->nan_both, 2 * sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
     use_state(c, 0);
-    c->tiles_x = (width + kTile - 1) / kTile;
-    c->tiles_y = (height + kTile - 1) / kTile;
+    if (const char* e = std::getenv("TR_TILE")) {
+        int w = 0, h = 0;
+        if (std::sscanf(e, "%dx%d", &w, &h) == 2 &&
+            ((w == 16 && h == 16) || (w == 32 && h == 16) || (w == 32 && h == 32) || (w == 64 && h == 32))) {
+            c->tile_w = w; c->tile_h = h;
+        }
+    }
+    for (c->tw_shift = 0; (1 << c->tw_shift) < c->tile_w; ++c->tw_shift) {}
+    for (c->th_shift = 0; (1 << c->th_shift) < c->tile_h; ++c->th_shift) {}
+    if (hipFuncSetAttribute((const void*)tile_kernel(c), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes(c)) != hipSuccess) return bail(TR_ERR_HIP);
+    c->tiles_x = (width + c->tile_w - 1) / c->tile_w;
+    c->tiles_y = (height + c->tile_h - 1) / c->tile_h;
     {
         size_t n_tiles = (size_t)c->tiles_x * c->tiles_y;
         const size_t quantum = 4 * (size_t)kTileScanThreads;
@@ -1254,7 +1276,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         sa.vpm = viewport_matrix(c->W, c->H);
         sa.nmat = nmat;
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
-        sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+        sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y; sa.tw_shift = c->tw_shift; sa.th_shift = c->th_shift;
         sa.small_res = 0;
         sa.small_flag = c->small_flag; sa.small_grp = c->small_grp;
         sa.y_lo = c->y_lo; sa.y_hi = c->y_hi; sa.mode = c->mode == 1 ? 2 : 1;  // (the row raster uses the global raster's slot sequence)
@@ -1431,7 +1453,7 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
         sa.tri_base = 0; sa.draw = 0; sa.W = c->W; sa.H = c->H;
         sa.vpm = viewport_matrix(c->W, c->H);
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
-        sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+        sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y; sa.tw_shift = c->tw_shift; sa.th_shift = c->th_shift;
         sa.small_flag = c->small_flag; sa.small_grp = c->small_grp;
         sa.y_lo = 0; sa.y_hi = c->H; sa.mode = 1;
         if (c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
@@ -1569,7 +1591,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             if (c->tri_total)
                 hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)(((uint64_t)c->tri_total * kFillLanes + 255) / 256)), dim3(256), 0, c->stream, c->rast,
                                    c->tri_total, c->tile_off, c->tile_cnt, c->pairs, c->pair_cap, c->tiles_x, c->y_lo,
-                                   c->y_hi);
+                                   c->y_hi, c->th_shift);
             TR_HIP(c, hipGetLastError());
         }
         if (c->tri_total) {
@@ -1584,17 +1606,8 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             if (const char* e = std::getenv("TR_TILE_DEBUG")) ta.debug = std::atoi(e);
             int grid = kTileGrid;
             if (const char* e = std::getenv("TR_TILE_GRID")) grid = std::atoi(e);
-            static bool printed = false;
-            if (ta.debug && !printed) {
-                printed = true;
-                int nb = 0;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_tile_raster, kTileThreads, 0);
-                hipFuncAttributes fa;
-                (void)hipFuncGetAttributes(&fa, (const void*)k_tile_raster);
-                std::fprintf(stderr, "k_tile_raster: occupancy %d blocks/CU, regs %d, lds %zu, grid %d\n", nb, fa.numRegs,
-                             fa.sharedSizeBytes, grid);
-            }
-            hipLaunchKernelGGL(k_tile_raster, dim3(grid), dim3(kTileThreads), 0, c->stream, ta);
+            hipLaunchKernelGGL(tile_kernel(c), dim3(grid), dim3(kTileThreads), tile_lds_bytes(c), c->stream, ta);
+            TR_HIP(c, hipGetLastError());
             TR_HIP(c, hipGetLastError());
         }
     }
@@ -1618,7 +1631,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         sa.rast = c->rast; sa.shade = c->shade; sa.draws = c->draw_table;
         sa.nan = c->mode == 0 ? c->nan : nullptr;
         sa.tile_off = c->mode == 1 ? c->tile_off : nullptr;
-        sa.tiles_x = c->tiles_x;
+        sa.tiles_x = c->tiles_x; sa.tw_shift = c->tw_shift; sa.th_shift = c->th_shift;
         sa.W = c->W; sa.H = c->H; sa.out_mask = out_mask; sa.rgba8 = c->rgba8; sa.z_out = c->z_out;
         sa.tri_out = c->tri_out; sa.rgba_f64 = c->rgba_f64; sa.flags = c->flags; sa.cov_counters = c->cov_counters;
         sa.blk_flags = c->blk_flags;

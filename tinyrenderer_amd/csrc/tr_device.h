@@ -31,7 +31,7 @@ struct Mat4 {  // column-major, m[c*4+r] (nalgebra storage order)
 struct __attribute__((aligned(128))) TriRaster {
     double s0[3], s1[3], s2[3], sp[3];
     uint32_t res[2];  // resolution of half 0 / half 1 (mod.rs:363-369); 0 = no scanlines
-    uint16_t tx0, ty0, tx1, ty1;  // inclusive rect of 16x16 tiles its samples can touch (tx0 > tx1: none)
+    uint16_t tx0, ty0, tx1, ty1;  // inclusive rect of the tile raster's tiles its samples can touch (tx0 > tx1: none)
     uint32_t flags;               // kTriNonFinite: x/y of a point is NaN/inf, no range pruning; kTriSmall
     uint32_t slot_shift;          // each scanline of this triangle occupies 1 << slot_shift slots of the
                                   // frame's slot sequence (load balance of the global raster, see k_setup)
@@ -44,7 +44,7 @@ constexpr uint32_t kTriFar = 4u;       // its centroid lies behind the draw's sp
 // per-triangle flag byte of the k_small / k_mid sweeps (small_flag): path in the low bits, kFlagFar on top
 constexpr uint8_t kFlagSmall = 1, kFlagMid = 2, kFlagPath = 3, kFlagFar = 4;
 constexpr uint32_t kSmallRes = 8u;
-constexpr int kTile = 16;             // screen tile edge in pixels
+constexpr int kTile = 16;             // granularity of a band's rows (tr_set_band) and the tile raster's smallest tile edge, in pixels
 constexpr double kPruneMargin = 1.0 / 64.0;  // slack (pixels) of every conservative range test
 static_assert(sizeof(TriRaster) == 128, "TriRaster must be 128 B");
 

@@ -56,6 +56,7 @@ struct SetupArgs {
     uint32_t* half_cnt;    // slots per half, 2 per triangle (global-atomic raster only)
     uint32_t* tile_cnt;    // triangles per tile (tile raster only)
     int tiles_x, tiles_y;
+    int tw_shift, th_shift; // log2 of the tile raster's tile width / height in pixels
     int y_lo, y_hi;        // band of pixel rows owned by this context
     int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small), bit4: flag mid ones (k_mid),
                            // bit3: no TriShade now (k_build_shade writes it for the triangles the winner pass flags)
@@ -474,8 +475,8 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
                 double rl = fmax(ceil(ymin - kPruneMargin - 0.5), (double)a.y_lo);
                 double rh = fmin(floor(ymax + kPruneMargin + 0.5), (double)(a.y_hi - 1));
                 if (cl <= ch && rl <= rh) {
-                    R.tx0 = (uint16_t)((int)cl / kTile); R.tx1 = (uint16_t)((int)ch / kTile);
-                    R.ty0 = (uint16_t)((int)rl / kTile); R.ty1 = (uint16_t)((int)rh / kTile);
+                    R.tx0 = (uint16_t)((int)cl >> a.tw_shift); R.tx1 = (uint16_t)((int)ch >> a.tw_shift);
+                    R.ty0 = (uint16_t)((int)rl >> a.th_shift); R.ty1 = (uint16_t)((int)rh >> a.th_shift);
                 }
             }
         }
@@ -503,7 +504,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         a.rast[seq] = R;
         if ((a.mode & 2) && res0) {
             if (R.flags & kTriNonFinite) {
-                int ty_lo = a.y_lo / kTile, ty_hi = (a.y_hi - 1) / kTile;
+                int ty_lo = a.y_lo >> a.th_shift, ty_hi = (a.y_hi - 1) >> a.th_shift;
                 if (ty_lo == 0)
                     for (int tx = 0; tx < a.tiles_x; ++tx) atomicAdd(&a.tile_cnt[tx], 1u);
                 for (int ty = (ty_lo > 1 ? ty_lo : 1); ty <= ty_hi; ++ty) atomicAdd(&a.tile_cnt[ty * a.tiles_x], 1u);
@@ -1694,6 +1695,7 @@ struct ShadeArgs {
     const NanTable* nan;        // global-atomic raster only (nullptr in tile mode)
     const uint32_t* tile_off;   // tile mode: a tile with an empty list has no keys in wkey
     int tiles_x;
+    int tw_shift, th_shift;  // tile mode: log2 of the tile size
     int W, H;
     uint32_t out_mask;
     uint32_t* rgba8;    // row-major, packed r | g<<8 | b<<16 | a<<24
@@ -1848,7 +1850,7 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     }
     bool listed = live;
     if (a.tile_off && live) {
-        int tile = (y / kTile) * a.tiles_x + (x / kTile);
+        int tile = (y >> a.th_shift) * a.tiles_x + (x >> a.tw_shift);
         listed = a.tile_off[tile + 1] > a.tile_off[tile];
     }
     unsigned long long key = listed ? a.wkey[ppix] : kKeyNone;

@@ -80,7 +80,7 @@ constexpr int kFillLanes = 16;
 __global__ __launch_bounds__(256) void k_bin_fill(const TriRaster* __restrict__ rast, uint32_t n_tris,
                                                   const uint32_t* __restrict__ tile_off, uint32_t* cursor,
                                                   uint32_t* pairs, uint32_t pair_cap, int tiles_x, int y_lo,
-                                                  int y_hi) {
+                                                  int y_hi, int th_shift) {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (n_tris * 16 may pass 2^32)
     const uint32_t k = (uint32_t)(gid / kFillLanes);
     const int q = (int)(gid % kFillLanes);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_bin_fill(const TriRaster* __restrict__ 
         if (pos < pair_cap) pairs[pos] = k;
     };
     if (r.flags & kTriNonFinite) {
-        int ty_lo = y_lo / kTile, ty_hi = (y_hi - 1) / kTile;
+        int ty_lo = y_lo >> th_shift, ty_hi = (y_hi - 1) >> th_shift;
         if (ty_lo == 0)
             for (int tx = q; tx < tiles_x; tx += kFillLanes) put(tx);
         for (int ty = (ty_lo > 1 ? ty_lo : 1) + q; ty <= ty_hi; ty += kFillLanes) put(ty * tiles_x);
@@ -198,10 +198,10 @@ constexpr int kOwnCap = 512;         // samples expanded per window (owner table
 constexpr int kUnroll = 4;           // samples per lane per step of the sample loop
 constexpr int kTileGrid = 256 * 3;   // persistent workgroups striding over the non-empty tiles
 
-// Local pixel coordinate (0..15) of `round(v) as i64` inside the 16-wide span starting at pixel
+// Local pixel coordinate (0..span-1) of `round(v) as i64` inside the span of `span` pixels starting at pixel
 // `lo`, or -1 when the rounded value falls outside the span or past `limit` (screen edge).
 // round() is half away from zero; v - floor(v) is exact for |v| < 2^52, NaN casts to 0.
-__device__ __forceinline__ int tile_coord(double v, int lo, int limit) {
+__device__ __forceinline__ int tile_coord(double v, int lo, int limit, int span) {
     double r;
     if (v != v) r = 0.0;
     else if (v < 0.0) r = (v > -0.5) ? 0.0 : -1.0;
@@ -210,7 +210,7 @@ __device__ __forceinline__ int tile_coord(double v, int lo, int limit) {
         r = (v - f >= 0.5) ? f + 1.0 : f;
     }
     double l = r - (double)lo;
-    if (!(l >= 0.0 && l <= (double)(kTile - 1)) || r > (double)(limit - 1)) return -1;
+    if (!(l >= 0.0 && l <= (double)(span - 1)) || r > (double)(limit - 1)) return -1;
     return (int)l;
 }
 
@@ -263,9 +263,14 @@ __device__ __forceinline__ void wave_lds_sync() {
 // which is exact because each holds its own minimum depth and the smallest key at that depth.
 // NaN depths (SURVEY.md 7.1 caveat i) are rare and handled by two extra enumerations on the
 // merged planes: first key over non-NaN samples, then NaN samples that precede it.
+// TW x TH: the tile's size in pixels (powers of two).  The private planes (kTileWaves x TW x TH x 16 B: 16 KB at 16 x 16,
+// 128 KB at 64 x 32 of the CU's 160 KB) are dynamic shared memory.
+template <int TW, int TH>
 __global__ __launch_bounds__(kTileThreads) void k_tile_raster(TileArgs a) {
-    __shared__ unsigned long long pDepth[kTileWaves][kTile * kTile];
-    __shared__ unsigned long long pKey[kTileWaves][kTile * kTile];
+    constexpr int kPix = TW * TH;
+    extern __shared__ __align__(16) unsigned long long s_planes[];
+    unsigned long long (*pDepth)[kPix] = reinterpret_cast<unsigned long long (*)[kPix]>(s_planes);
+    unsigned long long (*pKey)[kPix] = reinterpret_cast<unsigned long long (*)[kPix]>(s_planes + (size_t)kTileWaves * kPix);
     __shared__ LdsTri sTri[kBatchTris];
     __shared__ double sDelta[2 * kBatchTris];  // 1/res per half (segment_3d/mod.rs:110)
     __shared__ uint32_t sSeq[kBatchTris];      // tri_seq | nonfinite<<31
@@ -304,17 +309,16 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_raster(TileArgs a) {
         const uint32_t n_tri = list_hi - list_lo;
         if (a.debug == 1) continue;
 
-        const int px0 = tx * kTile, py0 = ty * kTile;
-        const double X0 = (double)px0 - 0.5 - kPruneMargin, X1 = (double)(px0 + kTile - 1) + 0.5 + kPruneMargin;
-        const double Y0 = (double)py0 - 0.5 - kPruneMargin, Y1 = (double)(py0 + kTile - 1) + 0.5 + kPruneMargin;
+        const int px0 = tx * TW, py0 = ty * TH;
+        const double X0 = (double)px0 - 0.5 - kPruneMargin, X1 = (double)(px0 + TW - 1) + 0.5 + kPruneMargin;
+        const double Y0 = (double)py0 - 0.5 - kPruneMargin, Y1 = (double)(py0 + TH - 1) + 0.5 + kPruneMargin;
         const int y_limit = a.y_hi < a.H ? a.y_hi : a.H;
         const long long t_start = (a.debug == 8) ? (long long)wall_clock64() : 0;
 
         __syncthreads();  // the previous tile's merge / write-out is done
-#pragma unroll
-        for (int w = 0; w < kTileWaves; ++w) {
-            pDepth[w][tid] = kKeyNone;
-            pKey[w][tid] = kKeyNone;
+        for (int p = tid; p < kTileWaves * kPix; p += kTileThreads) {
+            pDepth[0][p] = kKeyNone;  // (the planes of the four waves are contiguous)
+            pKey[0][p] = kKeyNone;
         }
         if (tid == 0) sNan = 0;
 
@@ -461,10 +465,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_raster(TileArgs a) {
                                 const double x = gA[0][g] + sp * gD[0][g];
                                 const double y = gA[1][g] + sp * gD[1][g];
                                 const double z = gA[2][g] + sp * gD[2][g];
-                                const int lx = tile_coord(x, px0, a.W);
-                                const int ly = tile_coord(y, py0, y_limit);
+                                const int lx = tile_coord(x, px0, a.W, TW);
+                                const int ly = tile_coord(y, py0, y_limit, TH);
                                 live[u] = live[u] && lx >= 0 && ly >= 0 && py0 + ly >= a.y_lo;
-                                lp[u] = live[u] ? ly * kTile + lx : 0;
+                                lp[u] = live[u] ? ly * TW + lx : 0;
                                 const double dist = -z;
                                 isnan_d[u] = dist != dist;
                                 enc[u] = encode_depth(dist);
@@ -514,16 +518,18 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_raster(TileArgs a) {
             __syncthreads();  // all samples of this phase have landed
             if (phase == 0) {
                 // merge the private planes: lexicographic (depth, key) minimum per pixel -> plane 0
-                unsigned long long d = pDepth[0][tid], k = pKey[0][tid];
+                for (int p = tid; p < kPix; p += kTileThreads) {
+                    unsigned long long d = pDepth[0][p], k = pKey[0][p];
 #pragma unroll
-                for (int w = 1; w < kTileWaves; ++w) {
-                    const unsigned long long dw = pDepth[w][tid], kw = pKey[w][tid];
-                    if (dw < d || (dw == d && kw < k)) { d = dw; k = kw; }
+                    for (int w = 1; w < kTileWaves; ++w) {
+                        const unsigned long long dw = pDepth[w][p], kw = pKey[w][p];
+                        if (dw < d || (dw == d && kw < k)) { d = dw; k = kw; }
+                    }
+                    pKey[0][p] = k;
+                    if (sNan) pDepth[0][p] = kKeyNone;
                 }
-                pKey[0][tid] = k;
                 if (!sNan) break;
                 phase = 2;
-                pDepth[0][tid] = kKeyNone;
             } else if (phase == 2) {
                 phase = 3;
             } else {
@@ -538,10 +544,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_raster(TileArgs a) {
             atomicMax(&a.counters[2], packed);
             atomicAdd(&a.counters[3], dt);
         }
-        // ---- write the tile's winner keys (rows of 16 keys = 128 contiguous bytes)
-        {
-            const int x = px0 + (tid & (kTile - 1)), y = py0 + (tid >> 4);
-            if (x < a.W && y < a.H) a.wkey[(size_t)y * a.W + x] = pKey[0][tid];
+        // ---- write the tile's winner keys (rows of TW keys: 128 contiguous bytes and more)
+        for (int p = tid; p < kPix; p += kTileThreads) {
+            const int x = px0 + (p & (TW - 1)), y = py0 + p / TW;
+            if (x < a.W && y < a.H) a.wkey[(size_t)y * a.W + x] = pKey[0][p];
         }
     }
 #pragma unroll
@@ -559,5 +565,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile_raster(TileArgs a) {
         atomicAdd(&slot[7], cnt_steps);  // lane-steps of the sample loop
     }
 }
+
+template __global__ void k_tile_raster<16, 16>(TileArgs);
+template __global__ void k_tile_raster<32, 16>(TileArgs);
+template __global__ void k_tile_raster<32, 32>(TileArgs);
+template __global__ void k_tile_raster<64, 32>(TileArgs);
 
 }  // namespace tr
