@@ -240,6 +240,17 @@ int tr_select_view(tr_context* ctx, int view);
 int tr_set_band(tr_context* ctx, int y_lo, int y_hi);
 int tr_set_raster_mode(tr_context* ctx, int mode);
 
+/* Colour arithmetic of the fragment stage (src/main.rs:173-267, src/model_renderer/mod.rs:499-504).  By default
+ * everything after the barycentrics and the texture coordinates -- normal interpolation and normalisation, the
+ * bilinear sums of helpers::sample_nd_img (src/helpers/mod.rs:263-270), the TBN product, the Lambert term -- may fuse
+ * multiply-adds and use the hardware's reciprocal square root (still binary64): the presented RGBA8 is then within
+ * +-1 LSB of the reference's, the bar for colour.  exact != 0 (or TR_SHADE_EXACT=1 in the environment at tr_create)
+ * evaluates those steps operation for operation as the reference does: 0 LSB, f64 colour bit for bit.  Depth, winner
+ * keys, triangle ids and texel addresses are exact either way; a resolve that asks for TR_OUT_RGBA_F64 and frames
+ * with extension shaders always use the exact arithmetic.  May be called at any time; a frame already resolved is
+ * shaded again by the next read of its colour. */
+int tr_set_colour_exact(tr_context* ctx, int exact);
+
 /* Plumbing for callers that keep data on the GPU (no reference analogue). */
 int tr_synchronize(tr_context* ctx);
 int tr_get_stream(tr_context* ctx, void** out_hip_stream);

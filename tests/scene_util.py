@@ -67,6 +67,17 @@ def gpu_render(W, H, draws, device=0, mode=None, band=None):
                "seq": st.triangle_ids().astype(np.int64), "present": st.present(),
                "counters": st.counters(), "flags": st.status_flags()}
         out["seq"][out["seq"] == 0xFFFFFFFF] = -1
+        # the same frame once more the way a frame loop renders it: RGBA8 only, the library's fused colour arithmetic
+        # (tr_set_colour_exact(0): +-1 LSB; the resolve above asked for the f64 colour plane and so shaded exactly)
+        st.set_colour_exact(False)
+        clear_screen(st)
+        if band is not None:
+            st.set_band(*band)
+        for draw in draws:
+            render_mesh_component(st, draw[0], draw[1], draw[2] if len(draw) > 2 else None)
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        out["present_fused"] = st.present()
+        out["flags"] |= st.status_flags()
         return out
     finally:
         st.close()
@@ -83,7 +94,12 @@ def assert_parity(o, g, color_lsb=1):
     assert (o["key"] == g["key"]).all(), f"{(o['key'] != g['key']).sum()} winner-key mismatches"
     d = np.abs(o["present"].astype(np.int16) - g["present"].astype(np.int16))
     assert d.max() <= color_lsb, f"presented colour differs by {d.max()} LSB"
+    fused_lsb, fused_px = 0, 0
+    if "present_fused" in g:  # the default (fused) colour arithmetic: the same bar, +-1 LSB
+        df = np.abs(o["present"].astype(np.int16) - g["present_fused"].astype(np.int16))
+        assert df.max() <= 1, f"fused colour arithmetic differs by {df.max()} LSB at {np.argwhere(df > 1)[:5].tolist()}"
+        fused_lsb, fused_px = int(df.max()), int((df.max(axis=-1) > 0).sum())
     fo, fg = o["fb"], g["fb"]
     exact = (fo.view(np.uint64) == fg.view(np.uint64)) | (np.isnan(fo) & np.isnan(fg))
-    return {"max_lsb": int(d.max()), "f64_colour_mismatches": int((~exact).sum()),
+    return {"max_lsb": int(d.max()), "fused_max_lsb": fused_lsb, "fused_pixels_off_by_one": fused_px, "f64_colour_mismatches": int((~exact).sum()),
             "covered": int(np.isfinite(zo).sum())}

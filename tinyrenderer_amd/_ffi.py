@@ -44,7 +44,7 @@ EXPORTS = [
     "tr_obj_normals", "tr_obj_indices", "tr_obj_free", "tr_image_load_rgba8", "tr_image_size", "tr_image_data",
     "tr_image_free", "tr_load_error", "tr_image_write_png", "tr_selftest_arithmetic",
     "tr_draw_ext", "tr_shadow_map_create", "tr_shadow_map_update", "tr_shadow_map_destroy", "tr_host_alloc", "tr_host_free",
-    "tr_read_rgba8_static", "tr_create_views", "tr_render_views", "tr_select_view",
+    "tr_read_rgba8_static", "tr_create_views", "tr_render_views", "tr_select_view", "tr_set_colour_exact",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
         "tr_version": (C.c_char_p, []),
         "tr_set_band": (i32, [vp, i32, i32]),
         "tr_set_raster_mode": (i32, [vp, i32]),
+        "tr_set_colour_exact": (i32, [vp, i32]),
         "tr_obj_load": (i32, [C.c_char_p, C.POINTER(vp)]),
         "tr_obj_parse": (i32, [C.c_char_p, i64, C.POINTER(vp)]),
         "tr_obj_counts": (i32, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),

@@ -75,6 +75,7 @@ struct tr_context {
     bool split_any = false;   // a draw of this frame did
     bool plane_tiles = true;   // TR_PLANE_TILES: frames whose first draw uses k_small keep their planes in 4 x 2 tiles
     bool frame_tiled = false;  // this frame does
+    bool colour_exact = false;  // TR_SHADE_EXACT / tr_set_colour_exact: k_shade's colour arithmetic operation for operation (0 LSB) instead of fused (+-1 LSB)
     bool shade_box = true;  // TR_SHADE_BOX: the cheap resolve launches the blocks of frame_box + paint_box only
     // batched views (tr_create_views / tr_render_views): the planes hold max_views slices of W x H pixels
     int max_views = 1;
@@ -759,6 +760,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (const char* e = std::getenv("TR_DEPTH_SPLIT")) c->depth_split = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_PLANE_TILES")) c->plane_tiles = std::atoi(e) != 0;
     if (const char* e = std::getenv("TR_SHADE_BOX")) c->shade_box = std::atoi(e) != 0;
+    if (const char* e = std::getenv("TR_SHADE_EXACT")) c->colour_exact = std::atoi(e) != 0;
     c->max_views = max_views;
     c->n_views = max_views;  // (an empty frame resolves every slice)
     c->npix_all = (size_t)width * height * (size_t)max_views;
@@ -1699,8 +1701,12 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         c->shaded_hi = c->y_hi;
         sa.trace = nullptr;
         static const char* shade_trace = std::getenv("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
+        // the fused colour arithmetic (+-1 LSB) unless the caller asked for the reference's operations or for the f64 colour plane
+        const bool fast = !c->colour_exact && !(out_mask & TR_OUT_RGBA_F64);
         if (views) {
-            if (!nothing) hipLaunchKernelGGL((k_shade<false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+            if (nothing) {}
+            else if (fast) hipLaunchKernelGGL((k_shade<false, false, true, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+            else hipLaunchKernelGGL((k_shade<false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         } else if (shade_trace && !c->frame_has_ext) {
             const size_t words = (size_t)sgrid.x * sgrid.y * 4 * 4;
             static unsigned long long* buf = nullptr;
@@ -1734,7 +1740,9 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
                 TR_HIP(c, hipEventRecord(it->second, c->stream));
             }
         }
-        else if (!nothing) hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        else if (nothing) {}
+        else if (fast) hipLaunchKernelGGL((k_shade<false, false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }
     if (c->mode != 1 && out_mask == TR_OUT_RGBA8) {
@@ -1910,6 +1918,16 @@ int tr_set_band(tr_context* c, int y_lo, int y_hi) {
     if (c->max_views > 1 && (y_lo != 0 || y_hi != c->H)) return fail(c, TR_ERR_UNSUPPORTED, "no bands on a tr_create_views context");
     c->y_lo = y_lo;
     c->y_hi = y_hi;
+    return TR_OK;
+}
+
+int tr_set_colour_exact(tr_context* c, int exact) {
+    if (!c) return TR_ERR_INVALID;
+    if ((exact != 0) != c->colour_exact) {
+        c->colour_exact = exact != 0;
+        // what is resolved was shaded the other way: the next read of the colour plane shades again
+        if (c->resolved) c->resolved_mask &= ~(uint32_t)(TR_OUT_RGBA8 | TR_OUT_RGBA_F64);
+    }
     return TR_OK;
 }
 

@@ -1722,8 +1722,12 @@ struct ShadeArgs {
 };
 
 // helpers/mod.rs:253-278 on an RGBA8 image (texel value as f64 is exact).  Channels r,g,b.
-__device__ __forceinline__ void sample_rgb(const uint32_t* __restrict__ img, int W, int H, double x,
-                                           double y, double out[3], uint32_t* flags) {
+// The four texels and their weights (the weights use f64 x1, x2; the indices their saturated casts).
+struct Taps {
+    uint32_t c00, c10, c01, c11;
+    double w00, w10, w01, w11;
+};
+__device__ __forceinline__ Taps sample_taps(const uint32_t* __restrict__ img, int W, int H, double x, double y, uint32_t* flags) {
     double x1 = floor(x), y1 = floor(y);
     // `x1 as usize`: NaN / negative -> 0, saturating above (any index >= 2^32 - 1 is out of range either way)
     uint32_t ix1 = f64_as_u32_sat(x1);
@@ -1738,22 +1742,52 @@ __device__ __forceinline__ void sample_rgb(const uint32_t* __restrict__ img, int
         if (ix1 >= (uint32_t)W) ix1 = (uint32_t)(W - 1);
         if (iy1 >= (uint32_t)H) iy1 = (uint32_t)(H - 1);
     }
-    uint32_t c00 = img[(size_t)iy1 * W + ix1];
-    uint32_t c10 = img[(size_t)iy1 * W + ix2];
-    uint32_t c01 = img[(size_t)iy2 * W + ix1];
-    uint32_t c11 = img[(size_t)iy2 * W + ix2];
-    double w00 = (x2 - x) * (y2 - y);
-    double w10 = (x - x1) * (y2 - y);
-    double w01 = (x2 - x) * (y - y1);
-    double w11 = (x - x1) * (y - y1);
+    Taps t;
+    t.c00 = img[(size_t)iy1 * W + ix1];
+    t.c10 = img[(size_t)iy1 * W + ix2];
+    t.c01 = img[(size_t)iy2 * W + ix1];
+    t.c11 = img[(size_t)iy2 * W + ix2];
+    t.w00 = (x2 - x) * (y2 - y);
+    t.w10 = (x - x1) * (y2 - y);
+    t.w01 = (x2 - x) * (y - y1);
+    t.w11 = (x - x1) * (y - y1);
+    return t;
+}
+__device__ __forceinline__ void blend_taps(const Taps& t, double out[3]) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        double a = (double)((c00 >> (8 * ch)) & 0xFFu);
-        double b = (double)((c10 >> (8 * ch)) & 0xFFu);
-        double c = (double)((c01 >> (8 * ch)) & 0xFFu);
-        double d = (double)((c11 >> (8 * ch)) & 0xFFu);
-        out[ch] = a * w00 + b * w10 + c * w01 + d * w11;
+        double a = (double)((t.c00 >> (8 * ch)) & 0xFFu);
+        double b = (double)((t.c10 >> (8 * ch)) & 0xFFu);
+        double c = (double)((t.c01 >> (8 * ch)) & 0xFFu);
+        double d = (double)((t.c11 >> (8 * ch)) & 0xFFu);
+        out[ch] = a * t.w00 + b * t.w10 + c * t.w01 + d * t.w11;
     }
+}
+// The same sum with fused multiply-adds (k_shade's FAST colour arithmetic: within an ulp or two of blend_taps).
+__device__ __forceinline__ void blend_taps_fused(const Taps& t, double out[3]) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        double a = (double)((t.c00 >> (8 * ch)) & 0xFFu);
+        double b = (double)((t.c10 >> (8 * ch)) & 0xFFu);
+        double c = (double)((t.c01 >> (8 * ch)) & 0xFFu);
+        double d = (double)((t.c11 >> (8 * ch)) & 0xFFu);
+        out[ch] = __builtin_fma(d, t.w11, __builtin_fma(c, t.w01, __builtin_fma(b, t.w10, a * t.w00)));
+    }
+}
+__device__ __forceinline__ void sample_rgb(const uint32_t* __restrict__ img, int W, int H, double x,
+                                           double y, double out[3], uint32_t* flags) {
+    const Taps t = sample_taps(img, W, H, x, y, flags);
+    blend_taps(t, out);
+}
+// v / |v| with the hardware's reciprocal square root and one Newton step (relative error ~1e-14) instead of a
+// correctly rounded square root and three correctly rounded divisions.  A zero or infinite vector gives NaNs, as the
+// exact form does.
+__device__ __forceinline__ void normalize3_fast(double& x, double& y, double& z) {
+    const double s = __builtin_fma(z, z, __builtin_fma(y, y, x * x));
+    double r = __builtin_amdgcn_rsq(s);
+    const double e = __builtin_fma(-(0.5 * s) * r, r, 0.5);
+    r = __builtin_fma(r, e, r);
+    x *= r; y *= r; z *= r;
 }
 
 // Loads from a wave-uniform address through the scalar cache (constant address space).  The data
@@ -1802,7 +1836,12 @@ __device__ __forceinline__ double pow_exponent(double x, double e) {
 // still get the reference's formula, operation for operation.
 // VIEWS: a batch of views of one mesh, stacked in y (tr_render_views); a wave's pixels belong to one view, whose
 // fragment constants come through the scalar cache.
-template <bool EXT, bool TRACE = false, bool VIEWS = false>
+// FAST: the colour arithmetic AFTER the barycentrics and the texture coordinates may fuse multiply-adds and use the
+// hardware's reciprocal square root (still f64): the presented colour stays within +-1 LSB of the reference's (the
+// bar BASELINE.json sets for RGB) instead of equal to it.  The winning sample's position, the barycentrics, u and v --
+// everything a texel ADDRESS or the depth plane depends on -- keep the reference's operations: sample_nd_img is
+// discontinuous where x reaches W - 1 exactly (helpers/mod.rs:255-270), and a corner sample has u exactly its vertex's.
+template <bool EXT, bool TRACE = false, bool VIEWS = false, bool FAST = false>
 __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     unsigned long long tr_t0 = 0;
     if (TRACE) tr_t0 = wall_clock64();
@@ -1899,10 +1938,18 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         double l2 = (((s.uy[2] - s.uy[0]) * (px - s.ux[2])) + ((s.ux[0] - s.ux[2]) * (py - s.uy[2]))) / det;
         double l3 = 1.0 - l1 - l2;
         // mod.rs:499-504
-        double nx = l1 * s.n[0][0] + l2 * s.n[1][0] + l3 * s.n[2][0];
-        double ny = l1 * s.n[0][1] + l2 * s.n[1][1] + l3 * s.n[2][1];
-        double nz = l1 * s.n[0][2] + l2 * s.n[1][2] + l3 * s.n[2][2];
-        normalize3(nx, ny, nz);
+        double nx, ny, nz;
+        if (FAST) {
+            nx = __builtin_fma(l3, s.n[2][0], __builtin_fma(l2, s.n[1][0], l1 * s.n[0][0]));
+            ny = __builtin_fma(l3, s.n[2][1], __builtin_fma(l2, s.n[1][1], l1 * s.n[0][1]));
+            nz = __builtin_fma(l3, s.n[2][2], __builtin_fma(l2, s.n[1][2], l1 * s.n[0][2]));
+            normalize3_fast(nx, ny, nz);
+        } else {
+            nx = l1 * s.n[0][0] + l2 * s.n[1][0] + l3 * s.n[2][0];
+            ny = l1 * s.n[0][1] + l2 * s.n[1][1] + l3 * s.n[2][1];
+            nz = l1 * s.n[0][2] + l2 * s.n[1][2] + l3 * s.n[2][2];
+            normalize3(nx, ny, nz);
+        }
         bool has_uv = s.flags & 1u, has_tb = s.flags & 2u;
         double u = 0.0, v = 0.0;
         if (has_uv) {  // mod.rs:510-514
@@ -1913,6 +1960,38 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         // take its constants from the kernel arguments, i.e. from SGPRs, instead of 112 B per lane
         // through the vector L1, which is the busiest unit of this kernel.
         auto finish = [&](const DrawDev& dp) __attribute__((always_inline)) {
+            if (FAST && !EXT) {
+                // main.rs:183-265 with fused arithmetic
+                const bool use_nm = has_uv && has_tb && dp.use_nm;
+                Taps tn, tt;
+                if (use_nm) tn = sample_taps(dp.nm, dp.nw, dp.nh, u * (double)(dp.nw - 1), v * (double)(dp.nh - 1), a.flags);
+                if (use_nm) {
+                    double rgb[3];
+                    blend_taps_fused(tn, rgb);
+                    constexpr double k = 2.0 / 255.0;
+                    const double mx = __builtin_fma(rgb[0], k, -1.0), my = __builtin_fma(rgb[1], k, -1.0), mz = __builtin_fma(rgb[2], k, -1.0);
+                    double rx = __builtin_fma(nx, mz, __builtin_fma(s.b[0], my, s.t[0] * mx));
+                    double ry = __builtin_fma(ny, mz, __builtin_fma(s.b[1], my, s.t[1] * mx));
+                    double rz = __builtin_fma(nz, mz, __builtin_fma(s.b[2], my, s.t[2] * mx));
+                    normalize3_fast(rx, ry, rz);
+                    nx = rx; ny = ry; nz = rz;
+                }
+                double albedo[3];
+                if (has_uv) {
+                    // (requested here, not together with the normal map's texels: 70 instead of 84 VGPRs, 37.8 against 39.1 us at 4K)
+                    tt = sample_taps(dp.tex, dp.tw, dp.th, u * (double)(dp.tw - 1), v * (double)(dp.th - 1), a.flags);
+                    blend_taps_fused(tt, albedo);
+                } else {
+    #pragma unroll
+                    for (int c = 0; c < 3; ++c) albedo[c] = l1 * dp.vcol[c] + l2 * dp.vcol[c] + l3 * dp.vcol[c];
+                }
+                const double d = fmax(__builtin_fma(nz, dp.light[2], __builtin_fma(ny, dp.light[1], nx * dp.light[0])), 0.0);
+                const double di = d * dp.intensity;
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) col[c] = fmin(__builtin_fma(di, albedo[c], dp.ambient), 255.0);
+                col[3] = 255.0;
+                return;
+            }
             // main.rs:183-218
             if (has_uv && has_tb && dp.use_nm) {
                 double rgb[3];
@@ -2007,6 +2086,8 @@ template __global__ void k_shade<false, false>(ShadeArgs);
 template __global__ void k_shade<true, false>(ShadeArgs);
 template __global__ void k_shade<false, true>(ShadeArgs);
 template __global__ void k_shade<false, false, true>(ShadeArgs);
+template __global__ void k_shade<false, false, false, true>(ShadeArgs);
+template __global__ void k_shade<false, false, true, true>(ShadeArgs);
 
 __global__ void k_put_ext(DrawExt e, DrawExt* table, uint32_t draw) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[draw] = e;

@@ -192,8 +192,10 @@ class ModelRendererState:
     """src/model_renderer/mod.rs:29-35,150-173.  `frame_buffer` / `z_buffer` are read back from
     the GPU on access, in the reference's (W, H, C) layout."""
 
-    def __init__(self, frame_width, frame_height, device=0, raster_mode=None, max_views=1):
-        """`max_views` > 1: a state whose planes hold that many W x H slices, for `render_views`
+    def __init__(self, frame_width, frame_height, device=0, raster_mode=None, max_views=1, colour_exact=None):
+        """`colour_exact`: True = the fragment arithmetic operation for operation as the reference's (0 LSB), False = fused
+        (+-1 LSB, the library's default), None = the library's default or TR_SHADE_EXACT (tr_set_colour_exact).
+        `max_views` > 1: a state whose planes hold that many W x H slices, for `render_views`
         (tr_create_views; the reference renders one view per loop iteration, main.rs:57-116)."""
         self._lib = _ffi.load()
         self.frame_width = int(frame_width)
@@ -210,6 +212,8 @@ class ModelRendererState:
         self._ctx = ctx
         if raster_mode is not None:
             _ffi.check(ctx, self._lib.tr_set_raster_mode(ctx, int(raster_mode)), "tr_set_raster_mode")
+        if colour_exact is not None:
+            self.set_colour_exact(colour_exact)
         self._meshes = {}
         self._textures = {}
         self._keepalive = []
@@ -297,6 +301,10 @@ class ModelRendererState:
         """Restrict this context to pixel rows [y_lo, y_hi) (whole 16-pixel tile rows); call after
         clear_screen and before the first draw."""
         _ffi.check(self._ctx, self._lib.tr_set_band(self._ctx, int(y_lo), int(y_hi)), "tr_set_band")
+
+    def set_colour_exact(self, exact):
+        """tr_set_colour_exact: the reference's colour arithmetic operation for operation (True) or fused (False)."""
+        _ffi.check(self._ctx, self._lib.tr_set_colour_exact(self._ctx, 1 if exact else 0), "tr_set_colour_exact")
 
     def resolve(self, out_mask=_ffi.TR_OUT_RGBA8):
         _ffi.check(self._ctx, self._lib.tr_resolve(self._ctx, out_mask), "tr_resolve")
