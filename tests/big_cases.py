@@ -81,9 +81,16 @@ def gpu_planes(W, H, draws, band=None, device=0, state=None):
         st.set_band(*(band if band is not None else (0, H)))  # (a reused state keeps its last band otherwise)
         for d in draws:
             render_mesh_component(st, d[0], d[1])
+        # the digests are of the reference's colour arithmetic; the library's default (fused) must stay within 1 LSB of it
+        st.set_colour_exact(True)
         st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z | _ffi.TR_OUT_KEY)
         assert st.status_flags() == 0
-        return st.z_row_major(), st.winner_keys(_ffi.TR_LAYOUT_ROW_MAJOR), st.present(), st.counters()
+        out = st.z_row_major(), st.winner_keys(_ffi.TR_LAYOUT_ROW_MAJOR), st.present(), st.counters()
+        if not SU.exact_by_default():
+            st.set_colour_exact(False)
+            d = np.abs(st.present().astype(np.int16) - out[2].astype(np.int16))  # (shaded again from the same keys)
+            assert d.max() <= 1, f"fused colour arithmetic differs from the exact one by {d.max()} LSB"
+        return out
     finally:
         if state is None:
             st.close()

@@ -83,6 +83,57 @@ def gpu_render(W, H, draws, device=0, mode=None, band=None):
         st.close()
 
 
+def exact_by_default():
+    """TR_SHADE_EXACT=1 in the environment: contexts start with the reference's colour arithmetic."""
+    import os
+
+    return os.environ.get("TR_SHADE_EXACT", "0") not in ("", "0")
+
+
+def assert_image(got, want, what=""):
+    """An image rendered with the library's DEFAULT colour arithmetic (fused: within 1 LSB of the oracle's; equal
+    when TR_SHADE_EXACT=1 makes the reference's arithmetic the default)."""
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    lim = 0 if exact_by_default() else 1
+    assert d.max() <= lim, f"{what}: {int((d.max(axis=-1) > lim).sum())} pixels differ by up to {d.max()} LSB, first {np.argwhere(d > lim)[:5].tolist()}"
+
+
+def check_present(st, want, what=""):
+    """The presented image of a resolved state against the oracle's `want`: within 1 LSB with the library's default
+    (fused) colour arithmetic, equal with the reference's (tr_set_colour_exact: the frame is shaded again)."""
+    got = st.present()
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"{what}: presented colour differs by {d.max()} LSB at {np.argwhere(d > 1)[:5].tolist()}"
+    if not exact_by_default():
+        st.set_colour_exact(True)
+        try:
+            exact = st.present()
+        finally:
+            st.set_colour_exact(False)
+        assert np.array_equal(exact, want), f"{what}: exact colour arithmetic differs from the oracle's image"
+    else:
+        assert np.array_equal(got, want), f"{what}: presented image"
+
+
+def check_present_digest(st, want_sha, what=""):
+    """The same against a SHA-256 of the oracle's presented image (full-size frames): the exact arithmetic must hash to
+    it, the default (fused) one must stay within 1 LSB of the exact image."""
+    import hashlib
+
+    got = st.present()
+    if not exact_by_default():
+        st.set_colour_exact(True)
+        try:
+            exact = st.present()
+        finally:
+            st.set_colour_exact(False)
+        d = np.abs(got.astype(np.int16) - exact.astype(np.int16))
+        assert d.max() <= 1, f"{what}: fused colour differs from the exact one by {d.max()} LSB"
+    else:
+        exact = got
+    assert hashlib.sha256(np.ascontiguousarray(exact)).hexdigest() == want_sha, f"{what}: presented image differs from the oracle's digest"
+
+
 def assert_parity(o, g, color_lsb=1):
     """Bit-exact depth / winner / triangle id; colour within `color_lsb` in the presented u8 domain."""
     assert g["flags"] == 0, f"status flags {g['flags']:#x}"

@@ -289,13 +289,13 @@ def test_frame_reuse_and_late_plane_requests(oracle, mode):
             clear_screen(st)
             render_mesh_component(st, *draws[0])
             st.resolve(_ffi.TR_OUT_RGBA8)                      # fast path
-            assert np.array_equal(st.present(), o1["present"])
+            SU.check_present(st, o1["present"])
             z = st.z_buffer[..., 0]                            # late request for another plane
             assert np.array_equal(z.view(np.uint64), o1["z"].view(np.uint64))
             assert np.array_equal(st.winner_keys(), o1["key"])
             render_mesh_component(st, *draws[1])               # extend the same frame
             st.resolve(_ffi.TR_OUT_RGBA8)
-            assert np.array_equal(st.present(), o2["present"])
+            SU.check_present(st, o2["present"])
             assert np.array_equal(st.winner_keys(), o2["key"])
             assert np.array_equal(st.z_buffer[..., 0].view(np.uint64), o2["z"].view(np.uint64))
         clear_screen(st)
@@ -430,7 +430,7 @@ def test_counters_over_an_extended_frame(oracle):
         c = st.counters()
         for k in ("samples", "fragments", "scanlines"):
             assert c[k] == o["counters"][k], k
-        assert np.array_equal(st.present(), o["present"])
+        SU.check_present(st, o["present"])
     finally:
         st.close()
 
@@ -494,10 +494,10 @@ def test_background_blocks_are_repainted_between_frames(oracle):
                 render_mesh_component(st, *d)
             st.resolve(_ffi.TR_OUT_RGBA8)
             want = SU.oracle_render(oracle, W, Hh, draws)["present"]
-            assert np.array_equal(st.present(), want), f"view {k}"
+            SU.check_present(st, want, str(f"view {k}"))
             if k == 3:  # a late plane request in between must not confuse the block flags
                 assert np.array_equal(st.winner_keys(), SU.oracle_render(oracle, W, Hh, draws)["key"])
-                assert np.array_equal(st.present(), want)
+                SU.check_present(st, want)
     finally:
         st.close()
         eye_mc.parent = head
@@ -576,13 +576,13 @@ def test_texture_destroyed_under_a_recorded_frame(oracle):
         st.resolve(_ffi.TR_OUT_RGBA8)
         tex = st._textures.pop(id(draws[0][0].texture))
         assert st._lib.tr_texture_destroy(st._ctx, tex) == 0
-        assert np.array_equal(st.present(), o["present"])       # resolved: still there
+        SU.assert_image(st.present(), o["present"])       # resolved: still there
         with pytest.raises(_ffi.TrError, match="destroyed"):
             st.z_buffer                                          # would shade again through the freed texture
         clear_screen(st)                                         # a new frame (the texture is uploaded again)
         render_mesh_component(st, *draws[0])
         assert np.array_equal(st.z_buffer[..., 0].view(np.uint64), o["z"].view(np.uint64))
-        assert np.array_equal(st.present(), o["present"])
+        SU.check_present(st, o["present"])
     finally:
         st.close()
 
@@ -621,7 +621,7 @@ def test_mid_triangle_path(oracle, monkeypatch):
         st.resolve(_ffi.TR_OUT_RGBA8)
         render_mesh_component(st, *draws[1])
         st.resolve(_ffi.TR_OUT_RGBA8)
-        assert np.array_equal(st.present(), o2["present"])
+        SU.check_present(st, o2["present"])
         assert np.array_equal(st.winner_keys(), o2["key"])
         c = st.counters()
         for k in ("samples", "fragments", "scanlines"):
@@ -687,20 +687,20 @@ def test_deferred_shade_records(oracle, monkeypatch):
             clear_screen(st)
             render_mesh_component(st, *draws[0])
             st.resolve(_ffi.TR_OUT_RGBA8)
-            assert np.array_equal(st.present(), o1["present"])
+            SU.check_present(st, o1["present"])
             assert np.array_equal(st.frame_buffer.view(np.uint64), o1["fb"].view(np.uint64))  # late plane: shaded again
             render_mesh_component(st, *draws[1])
             st.resolve(_ffi.TR_OUT_RGBA8)
-            assert np.array_equal(st.present(), o2["present"])
+            SU.check_present(st, o2["present"])
             # the head's mesh goes away under the recorded frame: resolved planes stay, a new resolve is refused
             mesh = st._meshes.pop(id(draws[0][0].mesh))
             assert st._lib.tr_mesh_destroy(st._ctx, mesh) == 0
-            assert np.array_equal(st.present(), o2["present"])
+            SU.assert_image(st.present(), o2["present"])
             with pytest.raises(_ffi.TrError, match="destroyed"):
                 st.frame_buffer
             clear_screen(st)
             render_mesh_component(st, *draws[0])
-            assert np.array_equal(st.present(), o1["present"])
+            SU.check_present(st, o1["present"])
         finally:
             st.close()
 
@@ -735,7 +735,7 @@ def test_small_triangle_path(oracle, monkeypatch):
         st.resolve(_ffi.TR_OUT_RGBA8)
         render_mesh_component(st, *draws[1])
         st.resolve(_ffi.TR_OUT_RGBA8)
-        assert np.array_equal(st.present(), o2["present"])
+        SU.check_present(st, o2["present"])
         assert np.array_equal(st.winner_keys(), o2["key"])
         assert st.counters()["samples"] == o2["counters"]["samples"]
     finally:
@@ -882,7 +882,7 @@ def test_boxed_shade_launch_follows_what_moves(oracle):
             else:
                 want = np.zeros((Hh, W, 4), dtype=np.uint8)
                 want[..., 3] = 255
-            assert np.array_equal(got, want), n
+            SU.assert_image(got, want, f"frame {n}")
             assert st.status_flags() == 0
     finally:
         st.close()
@@ -957,6 +957,6 @@ def test_tiled_planes_frame_with_every_raster_kernel(oracle):
             clear_screen(st)
             for d in draws:
                 render_mesh_component(st, *d)
-            assert np.array_equal(st.present(), o["present"])
+            SU.check_present(st, o["present"])
     finally:
         st.close()

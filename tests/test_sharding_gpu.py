@@ -92,9 +92,9 @@ def test_world2_real_gpu_bands_and_views_stitch_to_the_whole_frame(oracle, tmp_p
     o = SU.oracle_render(oracle, W, H, [(head, sh)])["present"]
     assert np.array_equal(whole, o)
     for name in ("full0", "full1"):  # the device plane is not flipped: row 0 = bottom
-        assert np.array_equal(got[name].view(np.uint8).reshape(H, W, 4)[::-1], whole), name
+        SU.assert_image(got[name].view(np.uint8).reshape(H, W, 4)[::-1], whole, name)
     mc = SU.component("diablo")
     mc.transform.set_rotation((0.0, 0.0, 0.0))
     for k in range(n_views):
         want = SU.oracle_render(oracle, W, H, [(mc, scenes.shader_for(mc, W, H, eye=scenes.orbit_eye(k, n_views)))])["present"]
-        assert np.array_equal(got["frames"][k].view(np.uint8).reshape(H, W, 4)[::-1], want), k
+        SU.assert_image(got["frames"][k].view(np.uint8).reshape(H, W, 4)[::-1], want, f"view {k}")

@@ -44,7 +44,7 @@ def _check_views(oracle, st, mc, shaders, W, H, mask=MASK):
         assert np.array_equal(np.where(tri >= 0, tri - v * n_tris, -1), o["seq"]), f"view {v}: triangle ids"
         fb = st.frame_buffer
         assert ((fb.view(np.uint64) == o["fb"].view(np.uint64)) | (np.isnan(fb) & np.isnan(o["fb"]))).all(), f"view {v}: f64 colour"
-        assert np.array_equal(st.present(), o["present"]), f"view {v}: presented image"
+        SU.check_present(st, o["present"], f"view {v}")
         for k in ("samples", "fragments", "scanlines"):
             total[k] += o["counters"][k]
         total["covered"] += int((o["key"] != B.NONE_KEY).sum())
@@ -75,11 +75,11 @@ def test_orbit_batch_matches_the_oracle_view_by_view(oracle):
             render_views(st, mc, shaders, _ffi.TR_OUT_RGBA8)
             for v, sh in enumerate(shaders):
                 st.select_view(v)
-                assert np.array_equal(st.present(), SU.oracle_render(oracle, W, H, [(mc, sh)])["present"]), v
+                SU.check_present(st, SU.oracle_render(oracle, W, H, [(mc, sh)])["present"], f"view {v}")
         st.select_view(4)
         o = SU.oracle_render(oracle, W, H, [(mc, shaders[4])])
         assert np.array_equal(_local_key(st.winner_keys(), 4, mc.mesh.triangles.shape[0]), o["key"])
-        assert np.array_equal(st.present(), o["present"])
+        SU.check_present(st, o["present"])
     finally:
         st.close()
 
@@ -143,7 +143,7 @@ def test_config5_orbit_views_1080p_as_one_batch():
             key = _local_key(st.winner_keys(_ffi.TR_LAYOUT_ROW_MAJOR), v, n_tris)
             assert B.sha(key) == want["key"] and int((key != B.NONE_KEY).sum()) == want["covered"], k
             assert B.sha(st.z_row_major().view(np.uint64)) == want["z"], k
-            assert B.sha(st.present()) == want["rgba8"], k
+            SU.check_present_digest(st, want["rgba8"], f"view {k}")
         for name in ("samples", "fragments", "scanlines"):
             assert tot[name] == sum(HASHES[f"c5_orbit_1080p_view{k}"]["counters"][name] for k in ks)
     finally:
@@ -195,6 +195,6 @@ def test_cheap_resolve_of_batches_of_changing_size_and_place(oracle):
             for v, s_ in enumerate(sh):
                 st.select_view(v)
                 want = SU.oracle_render(oracle, W, H, [(mc, s_)])["present"]
-                assert np.array_equal(st.present(), want), v
+                SU.check_present(st, want, f"view {v}")
     finally:
         st.close()

@@ -1705,7 +1705,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         const bool fast = !c->colour_exact && !(out_mask & TR_OUT_RGBA_F64);
         if (views) {
             if (nothing) {}
-            else if (fast) hipLaunchKernelGGL((k_shade<false, false, true, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+            else if (fast) hipLaunchKernelGGL((k_shade_fused<true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
             else hipLaunchKernelGGL((k_shade<false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         } else if (shade_trace && !c->frame_has_ext) {
             const size_t words = (size_t)sgrid.x * sgrid.y * 4 * 4;
@@ -1741,7 +1741,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             }
         }
         else if (nothing) {}
-        else if (fast) hipLaunchKernelGGL((k_shade<false, false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        else if (fast) hipLaunchKernelGGL((k_shade_fused<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
         TR_HIP(c, hipGetLastError());
     }

@@ -1743,10 +1743,23 @@ __device__ __forceinline__ Taps sample_taps(const uint32_t* __restrict__ img, in
         if (iy1 >= (uint32_t)H) iy1 = (uint32_t)(H - 1);
     }
     Taps t;
-    t.c00 = img[(size_t)iy1 * W + ix1];
-    t.c10 = img[(size_t)iy1 * W + ix2];
-    t.c01 = img[(size_t)iy2 * W + ix1];
-    t.c11 = img[(size_t)iy2 * W + ix2];
+    if (W >= 2) {
+        // ix2 is ix1 + 1 or, at the right edge, ix1 itself: the two texels of a row come as ONE 8-byte load from
+        // column min(ix1, W - 2) (the texture unit spends its cycles per wave-instruction, not per byte: PMC)
+        struct __attribute__((packed, aligned(4))) Pair { uint32_t lo, hi; };
+        const uint32_t bx = ix1 < (uint32_t)(W - 1) ? ix1 : (uint32_t)(W - 2);
+        const Pair r1 = *reinterpret_cast<const Pair*>(img + (size_t)iy1 * W + bx);
+        const Pair r2 = *reinterpret_cast<const Pair*>(img + (size_t)iy2 * W + bx);
+        t.c00 = ix1 == bx ? r1.lo : r1.hi;
+        t.c10 = ix2 == bx ? r1.lo : r1.hi;
+        t.c01 = ix1 == bx ? r2.lo : r2.hi;
+        t.c11 = ix2 == bx ? r2.lo : r2.hi;
+    } else {
+        t.c00 = img[(size_t)iy1 * W + ix1];
+        t.c10 = img[(size_t)iy1 * W + ix2];
+        t.c01 = img[(size_t)iy2 * W + ix1];
+        t.c11 = img[(size_t)iy2 * W + ix2];
+    }
     t.w00 = (x2 - x) * (y2 - y);
     t.w10 = (x - x1) * (y2 - y);
     t.w01 = (x2 - x) * (y - y1);
@@ -1841,8 +1854,17 @@ __device__ __forceinline__ double pow_exponent(double x, double e) {
 // bar BASELINE.json sets for RGB) instead of equal to it.  The winning sample's position, the barycentrics, u and v --
 // everything a texel ADDRESS or the depth plane depends on -- keep the reference's operations: sample_nd_img is
 // discontinuous where x reaches W - 1 exactly (helpers/mod.rs:255-270), and a corner sample has u exactly its vertex's.
-template <bool EXT, bool TRACE = false, bool VIEWS = false, bool FAST = false>
-__global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
+// STAGE: the records of the wave's distinct triangles (up to kStageTris of them: a 32 x 2 block of the reference's
+// scenes lies in two or three) are copied to LDS with three wave-wide 16-byte loads and read from there, instead of
+// ~24 loads per lane from global memory: the pass is bound by the texture unit's rate of wave-instructions (16 cycles
+// each whatever the lanes' addresses: TCP_TOTAL_CACHE_ACCESSES = 18.4 M per 4K launch = 72 k cycles per CU of a 92 k-cycle
+// launch).  Waves with more distinct triangles (meshes of triangles of a pixel) read them directly as before.
+constexpr int kStageTris = 8;
+constexpr int kStageStride = 512;  // bytes per staged triangle: TriRaster at 0, TriShade at 256 (its alignment)
+template <bool EXT, bool TRACE, bool VIEWS, bool FAST, bool STAGE>
+__device__ __forceinline__ void shade_body(const ShadeArgs& a) {
+    __shared__ __align__(256) unsigned char sStage[STAGE ? kStageTris * kStageStride : 256];
+    __shared__ uint32_t sStageTri[kStageTris];
     unsigned long long tr_t0 = 0;
     if (TRACE) tr_t0 = wall_clock64();
     auto trace_end = [&](uint32_t covered) {
@@ -1866,6 +1888,8 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     // (the depth / key planes may be tiled this frame; the output planes never are)
     const uint32_t ppix = (VIEWS ? view * a.view_pix : 0u) + plane_index((uint32_t)x, (uint32_t)y, (uint32_t)a.W, a.tiled != 0);
     const uint32_t blk = by * a.blocks_x + bx;
+    // (one scalar load for the whole kernel: the frame holds a NaN-depth sample -- a degenerate triangle's)
+    const bool nan_frame = a.nan && uniform_u32(&a.nan->pix[0]) != kNanEmpty;
     if (a.skip_clean) {
         // Nothing landed in this block: its keys are all "none".  If the previous frame left it
         // at the background colour too there is nothing to do; otherwise repaint the background.
@@ -1874,9 +1898,8 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         // of the waves that shade; measured, such waves lived 1.5 us and held half of the wave slots)
         // (both loads issued before either is needed: one round trip)
         const uint32_t f_both = uniform_u16(a.blk_flags + 2u * blk);
-        const uint32_t f_nan = uniform_u32(a.nan ? &a.nan->pix[0] : reinterpret_cast<const uint32_t*>(a.blk_flags));
         const uint32_t f_touched = f_both & 0xFFu, f_painted = f_both >> 8;
-        const bool touched = f_touched != 0 || (a.nan && f_nan != kNanEmpty);
+        const bool touched = f_touched != 0 || nan_frame;
         const bool painted = f_painted != 0;
         if (!touched && !painted) { trace_end(0xFFFFFFFFu); return; }  // (nobody writes the flags on this path)
         // (the workgroup is one wave: every lane has read the flags before lane 0 rewrites them)
@@ -1897,7 +1920,7 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         a.wkey[ppix] = kKeyNone;
         if (a.depth) a.depth[ppix] = kKeyNone;
     }
-    if (a.nan && live && a.nan->pix[0] != kNanEmpty) {
+    if (nan_frame && live) {
         for (uint32_t s = 0; s < kNanSlots; ++s)
             if (a.nan->pix[s] == ppix && a.nan->first_nan[s] < a.nan->first_any[s]) key = a.nan->first_nan[s];
     }
@@ -1909,21 +1932,59 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
         static_assert(kShadeBW * kShadeBH == 64, "the shade workgroup is one wave: votes instead of barriers");
         const bool any = nwin != 0ull;
         if (threadIdx.x == 0) {
-            if (a.out_mask & 1u) a.blk_flags[2u * blk + 1u] = any ? 1 : 0;  // (no colour plane written: what it holds is unchanged)
-            if (a.self_clean) a.blk_flags[2u * blk] = 0;
+            if ((a.out_mask & 1u) && a.self_clean) {  // (both bytes in one store)
+                *reinterpret_cast<uint16_t*>(a.blk_flags + 2u * blk) = any ? (uint16_t)0x0100u : (uint16_t)0u;
+            } else {
+                if (a.out_mask & 1u) a.blk_flags[2u * blk + 1u] = any ? 1 : 0;  // (no colour plane written: what it holds is unchanged)
+                if (a.self_clean) a.blk_flags[2u * blk] = 0;
+            }
+        }
+    }
+    uint32_t tri = has ? (uint32_t)(key >> kKeyTriShift) : 0xFFFFFFFFu;
+    uint32_t slot = 0;
+    bool staged = false;
+    if (STAGE && nwin) {
+        // the wave's distinct triangles, in the order of their first lanes
+        unsigned long long todo = __ballot(has);
+        uint32_t n_dist = 0;
+        while (todo && n_dist < (uint32_t)kStageTris) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tri, leader);
+            const bool mine = has && tri == t;
+            if (mine) slot = n_dist;
+            if ((int)threadIdx.x == leader) sStageTri[n_dist] = t;
+            todo &= ~__ballot(mine);
+            ++n_dist;
+        }
+        staged = todo == 0ull;  // (uniform)
+        if (staged) {
+            __syncthreads();  // (one wave: orders the list's writes before its reads)
+            // 16-byte chunks per triangle: the first 7 of TriRaster (points, split point, res) and the first 14 of TriShade
+            // (everything but the padding)
+            constexpr uint32_t kRastChunks = 7u, kChunks = 21u;
+            const uint32_t n_chunks = n_dist * kChunks;
+#pragma unroll
+            for (uint32_t c0 = 0; c0 < (uint32_t)kStageTris * kChunks; c0 += 64u) {
+                const uint32_t c = c0 + threadIdx.x;
+                if (c < n_chunks) {
+                    const uint32_t q = c / kChunks, part = c - q * kChunks;
+                    const uint32_t t = sStageTri[q];
+                    const uint4 v = part < kRastChunks ? reinterpret_cast<const uint4*>(a.rast + t)[part]
+                                                       : reinterpret_cast<const uint4*>(a.shade + t)[part - kRastChunks];
+                    reinterpret_cast<uint4*>(sStage + q * kStageStride)[part < kRastChunks ? part : part - kRastChunks + 16u] = v;
+                }
+            }
+            __syncthreads();
         }
     }
     if (!live) { trace_end(0u); return; }
     double col[4] = {0.0, 0.0, 0.0, 255.0};  // BLACK, helpers/mod.rs:22
     double zval = -__builtin_huge_val();
-    uint32_t tri = 0xFFFFFFFFu;
     if (has) {
-        tri = (uint32_t)(key >> kKeyTriShift);
         uint32_t half = (uint32_t)(key >> kKeyHalfShift) & 1u;
         uint32_t i = (uint32_t)(key >> kKeyIShift) & 0x1FFFFu;
         uint32_t j = (uint32_t)key & 0x3FFFFu;
-        const TriRaster& r = a.rast[tri];
-        const TriShade& s = a.shade[tri];
+      auto shade_px = [&](const TriRaster& r, const TriShade& s) __attribute__((always_inline)) {
         Scanline sl = make_scanline(r, half, i);
         double sp = (double)j * (1.0 / (double)sl.hres);
         double px = sl.ax + sp * sl.dx;
@@ -2068,6 +2129,12 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
             finish(uniform_drawdev(a.draws + view));  // (the batch's draws are its views, in order)
         } else if (__all(s.draw == 0u)) finish(a.draw0);  // kernel argument: scalar registers
         else finish(a.draws[s.draw]);
+      };
+        if (STAGE && staged)
+            shade_px(*reinterpret_cast<const TriRaster*>(sStage + slot * kStageStride),
+                     *reinterpret_cast<const TriShade*>(sStage + slot * kStageStride + 256));
+        else
+            shade_px(a.rast[tri], a.shade[tri]);
     }
     if (a.out_mask & 1u)
         a.rgba8[pix] = f64_as_u8(col[0]) | (f64_as_u8(col[1]) << 8) | (f64_as_u8(col[2]) << 16) |
@@ -2082,12 +2149,24 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
     if (TRACE) trace_end((uint32_t)__popcll(__ballot(has)));
 }
 
+// The exact kernels (records read per lane: staging them gains nothing where instruction issue bounds the pass --
+// 40.5 against 39.7 us) ...
+template <bool EXT, bool TRACE = false, bool VIEWS = false>
+__global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
+    shade_body<EXT, TRACE, VIEWS, false, false>(a);
+}
+// ... and the fused one, held to 64 VGPRs so that 8 waves fit a SIMD (no spills; 80 VGPRs and 6 waves otherwise:
+// 32.0 against 33.9 us at 4K)
+template <bool VIEWS>
+__global__ __launch_bounds__(kShadeBW * kShadeBH) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade_fused(ShadeArgs a) {
+    shade_body<false, false, VIEWS, true, true>(a);
+}
 template __global__ void k_shade<false, false>(ShadeArgs);
 template __global__ void k_shade<true, false>(ShadeArgs);
 template __global__ void k_shade<false, true>(ShadeArgs);
 template __global__ void k_shade<false, false, true>(ShadeArgs);
-template __global__ void k_shade<false, false, false, true>(ShadeArgs);
-template __global__ void k_shade<false, false, true, true>(ShadeArgs);
+template __global__ void k_shade_fused<false>(ShadeArgs);
+template __global__ void k_shade_fused<true>(ShadeArgs);
 
 __global__ void k_put_ext(DrawExt e, DrawExt* table, uint32_t draw) {
     if (threadIdx.x == 0 && blockIdx.x == 0) table[draw] = e;
