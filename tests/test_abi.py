@@ -60,3 +60,25 @@ def test_product_does_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read().lower()
                 for b in banned:
                     assert b not in text, f"{os.path.join(dirpath, f)} references {b!r}"
+
+
+def test_release_library_reads_only_the_documented_switches():
+    """The release build's environment surface is the table of INTEGRATION.md 4.1 and nothing else: the experiment,
+    trace and wrong-pixel switches live in the diagnostic build (`make diag`, -DTR_DIAG) only."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    start = text.index("### 4.1 Environment switches")
+    table = text[start:text.index("**Diagnostic build.**", start)]
+    documented = set(re.findall(r"`(TR_[A-Z0-9_]+)`", table))
+    assert {"TR_SHADE_EXACT", "TR_RASTER_MODE", "TR_TILE"} <= documented and len(documented) <= 12
+
+    def switches(path):
+        blob = open(path, "rb").read()
+        names = set(m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])TR_[A-Z][A-Z0-9_]+(?![A-Za-z0-9_])", blob))
+        return {n for n in names if not n.startswith(("TR_ERR", "TR_OUT", "TR_FLAG", "TR_LAYOUT", "TR_OK"))}
+
+    release = switches(_ffi.LIB_PATH if "diag" not in os.path.basename(_ffi.LIB_PATH) else os.path.join(ROOT, "tinyrenderer_amd", "libtinyrenderer_hip.so"))
+    assert release <= documented, f"undocumented switches in the release library: {sorted(release - documented)}"
+    diag = os.path.join(ROOT, "tinyrenderer_amd", "libtinyrenderer_hip_diag.so")
+    if os.path.exists(diag):
+        extra = switches(diag) - documented
+        assert {"TR_RASTER_DEBUG", "TR_DEBUG_PREFIX_STALL", "TR_SHADE_TRACE"} <= extra

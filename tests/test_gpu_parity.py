@@ -829,34 +829,53 @@ def test_context_lifecycle_leaves_no_device_memory_behind(oracle):
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory not returned"
 
 
-def test_fused_setup_prefix_poll_gives_up_instead_of_hanging(oracle, monkeypatch):
+_STALL_CHILD = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import scene_util as SU
+from tinyrenderer_amd import _ffi, scenes
+from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
+assert b"diag" in _ffi.load().tr_version()
+W, Hh = 320, 180
+head = SU.component("head")
+head.transform.set_rotation((0.025, 0.0, 0.0))
+st = ModelRendererState(W, Hh)
+t0 = time.perf_counter()
+clear_screen(st)
+render_mesh_component(st, head, scenes.shader_for(head, W, Hh))
+st.resolve(_ffi.TR_OUT_RGBA8)
+st.synchronize()
+assert time.perf_counter() - t0 < 20.0, "the bounded poll did not give up"
+assert st.status_flags() & _ffi.TR_FLAG_PREFIX_STALL, hex(st.status_flags())
+st.close()
+print("STALL-FLAG-SEEN")
+"""
+
+
+def test_fused_setup_prefix_poll_gives_up_instead_of_hanging(oracle):
     """k_setup<true> polls the slot totals of the workgroups before it; a word that never shows the launch's tag must end
-    in TR_FLAG_PREFIX_STALL after a bounded number of polls, not in a hang (TR_DEBUG_PREFIX_STALL makes the pollers wait
-    for a tag nobody publishes).  The context works again in the next frame of a context created without the switch."""
-    import time
+    in TR_FLAG_PREFIX_STALL after a bounded number of polls, not in a hang.  TR_DEBUG_PREFIX_STALL, which makes the pollers
+    wait for a tag nobody publishes, exists in the DIAGNOSTIC build only (a production process must not be able to ask
+    for incomplete frames through its environment): a child process loads that build.  The release build ignores the
+    switch."""
+    import os
+    import subprocess
+    import sys
 
-    from tinyrenderer_amd import _ffi
-    from tinyrenderer_amd.model_renderer import ModelRendererState, clear_screen, render_mesh_component
-
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TR_DEBUG_PREFIX_STALL="1", TINYRENDERER_HIP_DIAG="1")
+    env.pop("TINYRENDERER_HIP_LIB", None)
+    res = subprocess.run([sys.executable, "-c", _STALL_CHILD, root], env=env, capture_output=True, text=True, timeout=150)
+    assert res.returncode == 0 and "STALL-FLAG-SEEN" in res.stdout, res.stdout + res.stderr
     W, Hh = 320, 180
     draws = _head_scene(W, Hh, with_eye=False)
-    monkeypatch.setenv("TR_DEBUG_PREFIX_STALL", "1")
-    st = ModelRendererState(W, Hh)
+    os.environ["TR_DEBUG_PREFIX_STALL"] = "1"
     try:
-        t0 = time.perf_counter()
-        clear_screen(st)
-        for d in draws:
-            render_mesh_component(st, *d)
-        st.resolve(_ffi.TR_OUT_RGBA8)
-        st.synchronize()
-        assert time.perf_counter() - t0 < 20.0
-        assert st.status_flags() & _ffi.TR_FLAG_PREFIX_STALL
+        g = SU.gpu_render(W, Hh, draws)  # (this process holds the release build: the switch is not read)
     finally:
-        st.close()
-    monkeypatch.delenv("TR_DEBUG_PREFIX_STALL")
-    g = SU.gpu_render(W, Hh, draws)
+        del os.environ["TR_DEBUG_PREFIX_STALL"]
     o = SU.oracle_render(oracle, W, Hh, draws)
-    assert np.array_equal(g["present"], o["present"]) and np.array_equal(g["key"], o["key"])
+    SU.assert_parity(o, g)
 
 
 def test_boxed_shade_launch_follows_what_moves(oracle):

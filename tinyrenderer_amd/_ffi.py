@@ -7,8 +7,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (TINYRENDERER_HIP_LIB: an alternative build of the same library, for A/B timing)
-LIB_PATH = os.environ.get("TINYRENDERER_HIP_LIB") or os.path.join(_HERE, "libtinyrenderer_hip.so")
+# (TINYRENDERER_HIP_LIB: an alternative build of the same library, for A/B timing; TINYRENDERER_HIP_DIAG=1: the
+# diagnostic build, `make diag`, which alone reads the experiment / trace switches -- INTEGRATION.md 4.1)
+LIB_PATH = os.environ.get("TINYRENDERER_HIP_LIB") or os.path.join(
+    _HERE, "libtinyrenderer_hip_diag.so" if os.environ.get("TINYRENDERER_HIP_DIAG") == "1" else "libtinyrenderer_hip.so")
 
 TR_OK = 0
 TR_ERR = {

@@ -207,6 +207,17 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour);
 
 namespace {
 
+// Environment switches.  The release library reads the handful INTEGRATION.md documents (env_opt: capacities and path
+// thresholds, none of which changes a result).  Everything else -- kernels with their memory operations taken out,
+// per-chunk / per-wave timelines, forced poll failures, launch-shape experiments -- exists in the diagnostic build only
+// (`make diag`: -DTR_DIAG -> libtinyrenderer_hip_diag.so), which the tools/ scripts and one test load by name.
+inline const char* env_opt(const char* name) { return std::getenv(name); }
+#ifdef TR_DIAG
+inline const char* env_diag(const char* name) { return std::getenv(name); }
+#else
+inline const char* env_diag(const char*) { return nullptr; }
+#endif
+
 int fail(tr_context* c, int code, const std::string& msg) {
     if (c) {
         try { c->err = msg; }
@@ -456,7 +467,7 @@ int grow_records_for(tr_context* c, uint64_t n_tris) {
 }
 
 bool shade_trace_on() {
-    static const bool on = std::getenv("TR_SHADE_TRACE") != nullptr;
+    static const bool on = env_diag("TR_SHADE_TRACE") != nullptr;
     return on;
 }
 
@@ -499,13 +510,16 @@ void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block
         return;
     }
 #define TR_LAUNCH(PC, DB, TH) hipLaunchKernelGGL((k_raster<PASS, PC, DB, TH>), grid, block, 0, stream, ra)
-    if (threads == 128) {
-        if (dbg) { if (precheck) TR_LAUNCH(true, true, 128); else TR_LAUNCH(false, true, 128); }
-        else { if (precheck) TR_LAUNCH(true, false, 128); else TR_LAUNCH(false, false, 128); }
-    } else {
-        if (dbg) { if (precheck) TR_LAUNCH(true, true, 256); else TR_LAUNCH(false, true, 256); }
-        else { if (precheck) TR_LAUNCH(true, false, 256); else TR_LAUNCH(false, false, 256); }
+#ifdef TR_DIAG  // (the instantiations with the timing experiments and the per-chunk timeline exist in the diagnostic build only)
+    if (dbg) {
+        if (threads == 128) { if (precheck) TR_LAUNCH(true, true, 128); else TR_LAUNCH(false, true, 128); }
+        else { if (precheck) TR_LAUNCH(true, true, 256); else TR_LAUNCH(false, true, 256); }
+        return;
     }
+#endif
+    (void)dbg;
+    if (threads == 128) { if (precheck) TR_LAUNCH(true, false, 128); else TR_LAUNCH(false, false, 128); }
+    else { if (precheck) TR_LAUNCH(true, false, 256); else TR_LAUNCH(false, false, 256); }
 #undef TR_LAUNCH
 }
 
@@ -540,8 +554,8 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
     fill_raster_args(c, ra, h_lo, h_hi);
     ra.use_live = use_live && c->skip_dead ? 1 : 0;
     ra.rec_ready = rec_ready ? 1 : 0;
-    if (const char* e = std::getenv("TR_RASTER_DEBUG")) ra.debug = std::atoi(e);
-    static const char* trace_path = std::getenv("TR_RASTER_TRACE");  // debugging aid, see tools/raster_trace.py
+    if (const char* e = env_diag("TR_RASTER_DEBUG")) ra.debug = std::atoi(e);
+    static const char* trace_path = env_diag("TR_RASTER_TRACE");  // debugging aid, see tools/raster_trace.py
     static unsigned long long* trace_buf = nullptr;
     constexpr uint32_t kTraceCap = 1u << 16;
     if (trace_path) {
@@ -553,7 +567,7 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
     // workgroup size: see k_raster; frames in flight are recognised by a second live context on the device
     int threads = c->raster_threads ? c->raster_threads : (live_contexts(c->device).load() > 1 ? 128 : 256);
     int grid_blocks = kRasterWaves * 64 / threads;
-    if (const char* e = std::getenv("TR_RASTER_BLOCKS")) grid_blocks = std::atoi(e);
+    if (const char* e = env_diag("TR_RASTER_BLOCKS")) grid_blocks = std::atoi(e);
     dim3 grid(grid_blocks), block(threads);
     struct TraceDump {
         tr_context* c; int pass; const char* path; unsigned long long* buf;
@@ -732,7 +746,13 @@ int read_plane(tr_context* c, const T* dev, T* out, int layout, int comps) {
 
 extern "C" {
 
-const char* tr_version(void) { return "tinyrenderer_hip abi=4 arch=gfx950 fp=f64 contract=off"; }
+const char* tr_version(void) {
+#ifdef TR_DIAG
+    return "tinyrenderer_hip abi=5 arch=gfx950 fp=f64 contract=off diag";
+#else
+    return "tinyrenderer_hip abi=5 arch=gfx950 fp=f64 contract=off";
+#endif
+}
 
 const char* tr_last_error(const tr_context* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -757,38 +777,38 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     c->shaded_lo = 0;
     c->shaded_hi = height;
     c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = width; c->paint_box.y1 = height;
-    if (const char* e = std::getenv("TR_DEPTH_SPLIT")) c->depth_split = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_PLANE_TILES")) c->plane_tiles = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_SHADE_BOX")) c->shade_box = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_SHADE_EXACT")) c->colour_exact = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_DEPTH_SPLIT")) c->depth_split = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_PLANE_TILES")) c->plane_tiles = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_SHADE_BOX")) c->shade_box = std::atoi(e) != 0;
+    if (const char* e = env_opt("TR_SHADE_EXACT")) c->colour_exact = std::atoi(e) != 0;
     c->max_views = max_views;
     c->n_views = max_views;  // (an empty frame resolves every slice)
     c->npix_all = (size_t)width * height * (size_t)max_views;
-    if (const char* e = std::getenv("TR_RASTER_MODE"))
+    if (const char* e = env_opt("TR_RASTER_MODE"))
         c->mode = (std::strcmp(e, "tile") == 0 || std::strcmp(e, "1") == 0) ? 1
                   : (std::strcmp(e, "rows") == 0 || std::strcmp(e, "2") == 0) ? 2 : 0;
-    if (const char* e = std::getenv("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_RASTER_THREADS")) {
+    if (const char* e = env_diag("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
+    if (const char* e = env_opt("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
+    if (const char* e = env_opt("TR_RASTER_THREADS")) {
         const int t = std::atoi(e);
         if (t == 128 || t == 256) c->raster_threads = t;
     }
-    if (const char* e = std::getenv("TR_SMALL_TRIS")) c->small_path = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_SMALL_RES")) c->small_res = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TR_SMALL_DRAW")) c->small_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TR_MID_TRIS")) c->mid_path = std::atoi(e);
-    if (const char* e = std::getenv("TR_MID_PX")) c->mid_px = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TR_MID_SAMPLES")) c->mid_samples = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TR_DEBUG_PREFIX_STALL")) c->debug_prefix_stall = std::atoi(e) != 0;
-    if (const char* e = std::getenv("TR_DEFER_SHADE")) c->defer_tris = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char* e = std::getenv("TR_SCAN_RECORDS")) {
+    if (const char* e = env_diag("TR_SMALL_TRIS")) c->small_path = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_SMALL_RES")) c->small_res = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env_opt("TR_SMALL_DRAW")) c->small_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env_opt("TR_MID_TRIS")) c->mid_path = std::atoi(e);
+    if (const char* e = env_diag("TR_MID_PX")) c->mid_px = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env_opt("TR_MID_SAMPLES")) c->mid_samples = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env_diag("TR_BIG_DRAW")) c->big_draw_tris = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env_diag("TR_DEBUG_PREFIX_STALL")) c->debug_prefix_stall = std::atoi(e) != 0;
+    if (const char* e = env_opt("TR_DEFER_SHADE")) c->defer_tris = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env_opt("TR_SCAN_RECORDS")) {
         c->rec_cap = (uint32_t)std::strtoul(e, nullptr, 10);
         c->rec_auto = false;
     }
-    if (const char* e = std::getenv("TR_ROW_REFS")) c->ref_cap = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char* e = env_opt("TR_ROW_REFS")) c->ref_cap = (uint32_t)std::strtoul(e, nullptr, 10);
     if (c->ref_cap < 1) c->ref_cap = 1;
     if (max_views > 1) c->mode = 0;  // (batches of views exist in the global raster only)
     auto bail = [&](int code) {
@@ -822,7 +842,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (hipMalloc(&c->state_both, 2 * (size_t)kStateWords * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipMalloc(&c->nan_both, 2 * sizeof(NanTable)) != hipSuccess) return bail(TR_ERR_OOM);
     use_state(c, 0);
-    if (const char* e = std::getenv("TR_TILE")) {
+    if (const char* e = env_opt("TR_TILE")) {
         int w = 0, h = 0;
         if (std::sscanf(e, "%dx%d", &w, &h) == 2 &&
             ((w == 16 && h == 16) || (w == 32 && h == 16) || (w == 32 && h == 32) || (w == 64 && h == 32))) {
@@ -839,7 +859,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
         const size_t quantum = 4 * (size_t)kTileScanThreads;
         c->n_tiles_padded = (uint32_t)((n_tiles + quantum - 1) / quantum * quantum);
         c->pair_cap = 4u << 20;
-        if (const char* e = std::getenv("TR_TILE_PAIRS")) c->pair_cap = (uint32_t)std::strtoul(e, nullptr, 10);  // (tests: force a growth)
+        if (const char* e = env_opt("TR_TILE_PAIRS")) c->pair_cap = (uint32_t)std::strtoul(e, nullptr, 10);  // (tests: force a growth)
         if (c->pair_cap < 1) c->pair_cap = 1;
         if (hipMalloc(&c->tile_cnt, c->n_tiles_padded * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMalloc(&c->tile_off, ((size_t)c->n_tiles_padded + 4) * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
@@ -859,7 +879,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
         if (hipMalloc(&c->refs, (size_t)c->ref_cap * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
         if (hipMemsetAsync(c->bin_cnt, 0, (size_t)c->n_bins_padded * sizeof(uint32_t), c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     }
-    if (const char* e = std::getenv("TR_SHADE_SKIP_CLEAN")) c->skip_clean = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_SHADE_SKIP_CLEAN")) c->skip_clean = std::atoi(e) != 0;
     c->blocks_x = (width + kShadeBW - 1) / kShadeBW;
     c->blk_rows_per_view = (uint32_t)((height + kShadeBH - 1) / kShadeBH);
     c->blk_per_view = (uint32_t)c->blocks_x * c->blk_rows_per_view;
@@ -1346,7 +1366,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         }
         if (fused) {
             // (measured: 128 threads per workgroup; 64 / 256 cost the orbit rehearsal 1 % / 4 % with four contexts)
-            static const int st = std::getenv("TR_SETUP_THREADS") ? std::atoi(std::getenv("TR_SETUP_THREADS")) : 128;
+            static const int st = env_diag("TR_SETUP_THREADS") ? std::atoi(env_diag("TR_SETUP_THREADS")) : 128;
             const int threads = (st == 64 || st == 256) ? st : 128;
             hipLaunchKernelGGL((k_setup<true>), dim3((unsigned)((mesh->n_tris + threads - 1) / threads)), dim3(threads), 0, c->stream, sa);
         }
@@ -1561,9 +1581,9 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         {
             ProfScope ps(c, ST_WINNER);  // stage slot 4 = row raster
             int grid = kRowGrid;
-            if (const char* e = std::getenv("TR_ROW_GRID")) grid = std::atoi(e);
+            if (const char* e = env_diag("TR_ROW_GRID")) grid = std::atoi(e);
             ra.trace = nullptr; ra.trace_cap = 0;
-            static const char* trace_path = std::getenv("TR_RASTER_TRACE");
+            static const char* trace_path = env_diag("TR_RASTER_TRACE");
             static unsigned long long* trace_buf = nullptr;
             constexpr uint32_t kTraceCap = 1u << 16;
             if (trace_path) {
@@ -1605,9 +1625,9 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             ta.y_lo = c->y_lo; ta.y_hi = c->y_hi;
             ta.counters = c->counters; ta.flags = c->flags;
             ta.debug = 0;
-            if (const char* e = std::getenv("TR_TILE_DEBUG")) ta.debug = std::atoi(e);
+            if (const char* e = env_diag("TR_TILE_DEBUG")) ta.debug = std::atoi(e);
             int grid = kTileGrid;
-            if (const char* e = std::getenv("TR_TILE_GRID")) grid = std::atoi(e);
+            if (const char* e = env_diag("TR_TILE_GRID")) grid = std::atoi(e);
             hipLaunchKernelGGL(tile_kernel(c), dim3(grid), dim3(kTileThreads), tile_lds_bytes(c), c->stream, ta);
             TR_HIP(c, hipGetLastError());
             TR_HIP(c, hipGetLastError());
@@ -1700,14 +1720,17 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         c->shaded_lo = c->y_lo;
         c->shaded_hi = c->y_hi;
         sa.trace = nullptr;
-        static const char* shade_trace = std::getenv("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
+        static const char* shade_trace = env_diag("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
+        (void)shade_trace;
         // the fused colour arithmetic (+-1 LSB) unless the caller asked for the reference's operations or for the f64 colour plane
         const bool fast = !c->colour_exact && !(out_mask & TR_OUT_RGBA_F64);
         if (views) {
             if (nothing) {}
             else if (fast) hipLaunchKernelGGL((k_shade_fused<true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
             else hipLaunchKernelGGL((k_shade<false, false, true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
-        } else if (shade_trace && !c->frame_has_ext) {
+        }
+#ifdef TR_DIAG
+        else if (shade_trace && !c->frame_has_ext) {
             const size_t words = (size_t)sgrid.x * sgrid.y * 4 * 4;
             static unsigned long long* buf = nullptr;
             static size_t buf_words = 0;
@@ -1724,7 +1747,9 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             TR_HIP(c, hipStreamSynchronize(c->stream));
             TR_HIP(c, hipMemcpy(h.data(), buf, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             if (FILE* f = std::fopen(shade_trace, "wb")) { std::fwrite(h.data(), sizeof(unsigned long long), words, f); std::fclose(f); }
-        } else if (c->frame_has_ext) {
+        }
+#endif
+        else if (c->frame_has_ext) {
             for (tr_shadow_map* sm : c->frame_maps) TR_HIP(c, hipStreamWaitEvent(c->stream, sm->ready, 0));
             hipLaunchKernelGGL((k_shade<true>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
             for (tr_shadow_map* sm : c->frame_maps) {
@@ -1872,7 +1897,7 @@ int tr_get_counters(tr_context* c, uint64_t out[8]) {
     if (!c->resolved) out[4] = 0;
     if (c->mode == 1) out[2] = 0;  // scanlines / samples are not counted by the tile raster
     out[3] = c->tri_total;
-    if (std::getenv("TR_TILE_DEBUG") && std::atoi(std::getenv("TR_TILE_DEBUG")) == 8) {
+    if (env_diag("TR_TILE_DEBUG") && std::atoi(env_diag("TR_TILE_DEBUG")) == 8) {
         out[2] = tmp[2];
         out[3] = tmp[3];
     }

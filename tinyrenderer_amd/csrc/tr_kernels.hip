@@ -1670,18 +1670,20 @@ template __global__ void k_raster<0, true, false, 128>(RasterArgs);
 template __global__ void k_raster<1, true, false, 128>(RasterArgs);
 template __global__ void k_raster<0, false, false, 128>(RasterArgs);
 template __global__ void k_raster<1, false, false, 128>(RasterArgs);
-template __global__ void k_raster<0, true, true, 128>(RasterArgs);
-template __global__ void k_raster<1, true, true, 128>(RasterArgs);
-template __global__ void k_raster<0, false, true, 128>(RasterArgs);
-template __global__ void k_raster<1, false, true, 128>(RasterArgs);
 template __global__ void k_raster<0, true, false, 256>(RasterArgs);
 template __global__ void k_raster<1, true, false, 256>(RasterArgs);
 template __global__ void k_raster<0, false, false, 256>(RasterArgs);
 template __global__ void k_raster<1, false, false, 256>(RasterArgs);
+#ifdef TR_DIAG  // timing experiments (TR_RASTER_DEBUG) and the per-chunk timeline (TR_RASTER_TRACE)
+template __global__ void k_raster<0, true, true, 128>(RasterArgs);
+template __global__ void k_raster<1, true, true, 128>(RasterArgs);
+template __global__ void k_raster<0, false, true, 128>(RasterArgs);
+template __global__ void k_raster<1, false, true, 128>(RasterArgs);
 template __global__ void k_raster<0, true, true, 256>(RasterArgs);
 template __global__ void k_raster<1, true, true, 256>(RasterArgs);
 template __global__ void k_raster<0, false, true, 256>(RasterArgs);
 template __global__ void k_raster<1, false, true, 256>(RasterArgs);
+#endif
 
 // ================================================================ (4) shade
 struct ShadeArgs {
@@ -2163,7 +2165,9 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) __attribute__((amdgpu_waves_pe
 }
 template __global__ void k_shade<false, false>(ShadeArgs);
 template __global__ void k_shade<true, false>(ShadeArgs);
+#ifdef TR_DIAG  // per-wave timeline (TR_SHADE_TRACE)
 template __global__ void k_shade<false, true>(ShadeArgs);
+#endif
 template __global__ void k_shade<false, false, true>(ShadeArgs);
 template __global__ void k_shade_fused<false>(ShadeArgs);
 template __global__ void k_shade_fused<true>(ShadeArgs);

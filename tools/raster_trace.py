@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Per-chunk timeline of k_raster (debugging aid).  Run on the GPU box:
-    TR_RASTER_TRACE=gpurun_out/trace python tools/raster_trace.py [W H [head|diablo]]
+    TINYRENDERER_HIP_DIAG=1 TR_RASTER_TRACE=gpurun_out/trace python tools/raster_trace.py [W H [head|diablo]]
 renders a few frames of the bench scene (or of diablo3_pose), then summarises the last depth / winner launch."""
 import os
+
+os.environ.setdefault("TINYRENDERER_HIP_DIAG", "1")  # the trace switches exist in the diagnostic build only
 import sys
 
 import numpy as np

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Per-wave timeline of k_shade (debugging aid).  Run on the GPU box:
-    TR_SHADE_TRACE=gpurun_out/shade.trace python tools/shade_trace.py [W H]
+    TINYRENDERER_HIP_DIAG=1 TR_SHADE_TRACE=gpurun_out/shade.trace python tools/shade_trace.py [W H]
 renders a few frames of the bench scene and summarises the last shade launch: when waves with
 covered pixels start and end, how many are in flight per SIMD, how the launch trails off."""
 import os
+
+os.environ.setdefault("TINYRENDERER_HIP_DIAG", "1")  # the trace switches exist in the diagnostic build only
 import sys
 
 import numpy as np

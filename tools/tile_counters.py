@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: work counters of the tile raster for one frame of a scene (GPU needed)."""
 import os
+
+os.environ.setdefault("TINYRENDERER_HIP_DIAG", "1")  # TR_TILE_DEBUG exists in the diagnostic build only
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
