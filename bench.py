@@ -321,6 +321,7 @@ def main():
             # frame shaded operation for operation as the reference: that image must hash to the oracle's digest
             timed_img = s_.present().astype(np.int16)
             s_.set_colour_exact(True)
+            s_.resolve(_ffi.TR_OUT_RGBA8)  # (the mode holds from the next resolve on)
             exact_img = s_.present()
             s_.set_colour_exact(colour_exact_env)
             lsb = int(np.abs(timed_img - exact_img.astype(np.int16)).max())
@@ -426,10 +427,12 @@ def main():
         limit = float(os.environ.get("TR_BENCH_SECONDARY_LIMIT_S", "240"))
 
         def give_up():
+            # (a hang in the secondary records may be a hung collective or GPU: the headline line is still printed, but the
+            # process must not report success -- exit status 4, or 3 when the headline itself was not verified)
             if rank == 0:
                 out["secondary"].setdefault("error", f"not finished after {limit:.0f} s")
                 print(json.dumps(out), flush=True)
-            os._exit(3 if verified is False else 0)
+            os._exit(3 if verified is False else 4)
 
         watchdog = threading.Timer(limit + (0.0 if rank == 0 else 10.0), give_up)
         watchdog.daemon = True
@@ -440,12 +443,21 @@ def main():
             except Exception as e:
                 out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"}
         watchdog.cancel()
+    # a secondary record whose frame did not match its digest, or that raised, fails the run too (the line is printed first)
+    sec = out.get("secondary", {})
+    sec_bad = [n for n, r in sec.items() if isinstance(r, dict) and (r.get("verified") is False or "error" in r)]
+    if "error" in sec:
+        sec_bad.append("watchdog")
+    if sec_bad:
+        out["secondary_failed"] = sec_bad
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
     if verified is False:
         raise SystemExit(3)
+    if sec_bad:
+        raise SystemExit(5)
 
 
 if __name__ == "__main__":

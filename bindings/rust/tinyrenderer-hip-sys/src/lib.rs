@@ -15,6 +15,7 @@ pub const TR_ERR_NO_DEVICE: c_int = -3;
 pub const TR_ERR_OOM: c_int = -4;
 pub const TR_ERR_UNSUPPORTED: c_int = -5;
 pub const TR_ERR_SIZE: c_int = -6;
+pub const TR_ERR_BUSY: c_int = -7;
 
 pub const TR_FLAG_TRI_TOO_LARGE: u32 = 1 << 0;
 pub const TR_FLAG_REF_PANIC_SPLIT: u32 = 1 << 1;
@@ -117,6 +118,8 @@ extern "C" {
     // multi-GPU bands, strategy, plumbing
     pub fn tr_set_band(ctx: *mut tr_context, y_lo: c_int, y_hi: c_int) -> c_int;
     pub fn tr_set_raster_mode(ctx: *mut tr_context, mode: c_int) -> c_int;
+    // colour arithmetic of the fragment closure (main.rs:173-267): fused (+-1 LSB, default) or operation for operation (0 LSB)
+    pub fn tr_set_colour_exact(ctx: *mut tr_context, exact: c_int) -> c_int;
     pub fn tr_synchronize(ctx: *mut tr_context) -> c_int;
     pub fn tr_get_stream(ctx: *mut tr_context, out_hip_stream: *mut *mut c_void) -> c_int;
     pub fn tr_device_ptr_rgba8(ctx: *mut tr_context, out_dev_ptr: *mut *mut c_void) -> c_int;

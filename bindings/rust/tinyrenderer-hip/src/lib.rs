@@ -103,6 +103,14 @@ impl ModelRendererState {
     }
 
     /// Conditions the reference would have panicked or hung on (`TR_FLAG_*`), since the last clear.
+    /// Colour arithmetic of the fragment closure (src/main.rs:173-267): `false` (the library's default) lets it fuse
+    /// multiply-adds (presented RGBA8 within 1 LSB of this crate's reference), `true` evaluates it operation for
+    /// operation as `main.rs` does.  Depth and visibility are exact either way.
+    pub fn set_colour_exact(&mut self, exact: bool) {
+        let rc = unsafe { sys::tr_set_colour_exact(self.ctx, exact as i32) };
+        check(self.ctx, rc, "tr_set_colour_exact");
+    }
+
     pub fn status_flags(&mut self) -> u32 {
         let mut f = 0u32;
         let rc = unsafe { sys::tr_get_status_flags(self.ctx, &mut f) };

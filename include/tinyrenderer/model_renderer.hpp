@@ -111,6 +111,8 @@ class ModelRendererState {
     tr_context* context() { return ctx_; }
     // the slice of a render_views batch that z_buffer / frame_buffer / present refer to
     void select_view(int view) { check(tr_select_view(ctx_, view), "tr_select_view"); }
+    // colour arithmetic of the fragment closure (src/main.rs:173-267): fused (+-1 LSB, the default) or operation for operation
+    void set_colour_exact(bool exact) { check(tr_set_colour_exact(ctx_, exact ? 1 : 0), "tr_set_colour_exact"); }
 
     // state.z_buffer.nd_img: (W, H, 1) f64, -inf where nothing was drawn
     std::vector<double> z_buffer() {

@@ -39,7 +39,8 @@ enum {
     TR_ERR_NO_DEVICE = -3,    /* no usable GPU / kernels not loadable */
     TR_ERR_OOM = -4,
     TR_ERR_UNSUPPORTED = -5,  /* scene hit a documented limit, see tr_get_status_flags */
-    TR_ERR_SIZE = -6          /* size beyond a documented maximum */
+    TR_ERR_SIZE = -6,         /* size beyond a documented maximum */
+    TR_ERR_BUSY = -7          /* a shared resource is in use by another call (tr_read_rgba8_static); call again */
 };
 
 /* Bits of tr_get_status_flags(): conditions met on the device since tr_clear. */
@@ -196,13 +197,16 @@ int tr_read_triangle_id_u32(tr_context* ctx, uint32_t* out, int layout);
 int tr_read_winner_key_u64(tr_context* ctx, uint64_t* out, int layout);
 int tr_read_rgba8(tr_context* ctx, uint8_t* out, int flip);
 int tr_read_rgba_f64(tr_context* ctx, double* out, int layout);
-/* No counterpart in the reference.  tr_read_rgba8 for callers that CANNOT allocate device memory (code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): it never calls hipMalloc / hipFree,
- * resolves nothing (the frame must have been resolved with TR_OUT_RGBA8: TR_ERR_INVALID otherwise) and stages
- * the flipped image in a static device array of 3840 x 2160 pixels (33 177 600 B per GPU, held until the process
- * ends) instead of a buffer allocated on first use; larger frames: TR_ERR_SIZE.  Pass `out` from tr_host_alloc
- * for a copy the runtime does not stage either.  All contexts of a GPU share that array and it keeps the last
- * call's contents (every word handed to the caller is rewritten first): calls that overlap on one GPU race. */
+/* No counterpart in the reference.  tr_read_rgba8 for callers that CANNOT allocate device memory (serving loops,
+ * harnesses that forbid hipMalloc, code that must not allocate between the captures or replays of a HIP graph; the
+ * call itself synchronises the context's stream, so it is not for use INSIDE a capture): it never calls hipMalloc /
+ * hipFree, resolves nothing (the frame must have been resolved with TR_OUT_RGBA8: TR_ERR_INVALID otherwise) and
+ * stages the flipped image in a static device array of 3840 x 2160 pixels (33 177 600 B per GPU, held until the
+ * process ends) instead of a buffer allocated on first use; larger frames: TR_ERR_SIZE; a GPU on which the array's
+ * address could not be looked up: TR_ERR_UNSUPPORTED.  Pass `out` from tr_host_alloc for a copy the runtime does not
+ * stage either.  All contexts of a GPU share that array and it keeps the last call's contents (every word handed to
+ * the caller is rewritten first); one call at a time per GPU uses it: a call that arrives while another context's
+ * call on the same GPU is in progress returns TR_ERR_BUSY and may simply be made again. */
 int tr_read_rgba8_static(tr_context* ctx, uint8_t* out, int flip);
 /* Page-locked host memory for the read calls above (no counterpart in the reference): a device-to-host
  * copy into it runs at the link's rate instead of being staged (4K RGBA8: 0.7 ms instead of ~3 ms).
@@ -247,8 +251,9 @@ int tr_set_raster_mode(tr_context* ctx, int mode);
  * +-1 LSB of the reference's, the bar for colour.  exact != 0 (or TR_SHADE_EXACT=1 in the environment at tr_create)
  * evaluates those steps operation for operation as the reference does: 0 LSB, f64 colour bit for bit.  Depth, winner
  * keys, triangle ids and texel addresses are exact either way; a resolve that asks for TR_OUT_RGBA_F64 and frames
- * with extension shaders always use the exact arithmetic.  May be called at any time; a frame already resolved is
- * shaded again by the next read of its colour. */
+ * with extension shaders always use the exact arithmetic.  May be called at any time and holds from the next
+ * tr_resolve / tr_render_views on (a frame already resolved keeps the colours it was shaded with; tr_resolve again
+ * shades it the other way). */
 int tr_set_colour_exact(tr_context* ctx, int exact);
 
 /* Plumbing for callers that keep data on the GPU (no reference analogue). */

@@ -88,7 +88,8 @@ def gpu_planes(W, H, draws, band=None, device=0, state=None):
         out = st.z_row_major(), st.winner_keys(_ffi.TR_LAYOUT_ROW_MAJOR), st.present(), st.counters()
         if not SU.exact_by_default():
             st.set_colour_exact(False)
-            d = np.abs(st.present().astype(np.int16) - out[2].astype(np.int16))  # (shaded again from the same keys)
+            st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z | _ffi.TR_OUT_KEY)  # (shaded again from the same keys)
+            d = np.abs(st.present().astype(np.int16) - out[2].astype(np.int16))
             assert d.max() <= 1, f"fused colour arithmetic differs from the exact one by {d.max()} LSB"
         return out
     finally:

@@ -107,6 +107,7 @@ def check_present(st, want, what=""):
     if not exact_by_default():
         st.set_colour_exact(True)
         try:
+            st.resolve(_ffi.TR_OUT_RGBA8)  # (the mode holds from the next resolve on: shade the frame again)
             exact = st.present()
         finally:
             st.set_colour_exact(False)
@@ -124,6 +125,7 @@ def check_present_digest(st, want_sha, what=""):
     if not exact_by_default():
         st.set_colour_exact(True)
         try:
+            st.resolve(_ffi.TR_OUT_RGBA8)  # (the mode holds from the next resolve on: shade the frame again)
             exact = st.present()
         finally:
             st.set_colour_exact(False)

@@ -198,3 +198,28 @@ def test_cheap_resolve_of_batches_of_changing_size_and_place(oracle):
                 SU.check_present(st, want, f"view {v}")
     finally:
         st.close()
+
+
+def test_more_block_rows_times_views_than_a_grid_dimension_holds(oracle):
+    """The views shade launch has (block rows per view) x (views) workgroups rows: 551 x 120 = 66 120 > 65 535, the limit
+    of a grid dimension -- the views are the grid's z.  A narrow, tall frame; the first, a middle and the last view
+    against the oracle."""
+    W, H, n = 32, 1102, 120
+    mc = SU.component("head")
+    mc.transform.set_rotation((0.025, 0.0, 0.0))
+    shaders = [scenes.shader_for(mc, W, H, eye=(0.01 * (k - 60), 0.0, 2.0)) for k in range(n)]
+    st = ModelRendererState(W, H, max_views=n)
+    try:
+        assert ((H + 1) // 2) * n > 65535
+        for mask in (_ffi.TR_OUT_RGBA8, MASK):
+            render_views(st, mc, shaders, mask)
+            assert st.status_flags() == 0
+            for v in (0, 59, n - 1):
+                st.select_view(v)
+                o = SU.oracle_render(oracle, W, H, [(mc, shaders[v])])
+                assert (o["key"] != B.NONE_KEY).any()
+                SU.check_present(st, o["present"], f"view {v}")
+                if mask == MASK:
+                    assert np.array_equal(_local_key(st.winner_keys(), v, mc.mesh.triangles.shape[0]), o["key"]), v
+    finally:
+        st.close()

@@ -69,3 +69,59 @@ def test_static_read_refuses_frames_beyond_its_array():
         assert lib.tr_read_rgba8(st._ctx, out.ctypes.data, 1) == 0
     finally:
         st.close()
+
+
+def test_static_read_from_two_contexts_at_once_is_refused_not_raced():
+    """All contexts of a GPU share the staging array: two host threads, one context each (different frames), calling at the
+    same time.  A call either delivers exactly its own context's image or is refused with TR_ERR_BUSY and succeeds when
+    made again; never a mixture of the two frames."""
+    import threading
+
+    lib = _ffi.load()
+    W, H = 1920, 1080
+    head = SU.component("head")
+    states, wants = [], []
+    for rot in (0.025, 1.3):
+        head.transform.set_rotation((rot, 0.0, 0.0))
+        st = ModelRendererState(W, H)
+        clear_screen(st)
+        render_mesh_component(st, head, scenes.shader_for(head, W, H))
+        st.resolve(_ffi.TR_OUT_RGBA8)
+        st.synchronize()
+        want = np.empty((H, W, 4), dtype=np.uint8)
+        assert lib.tr_read_rgba8(st._ctx, want.ctypes.data, 1) == 0
+        states.append(st)
+        wants.append(want)
+    assert not np.array_equal(wants[0], wants[1])
+    results = [{"ok": 0, "busy": 0, "bad": 0, "other": []} for _ in states]
+    start = threading.Barrier(2)
+
+    def worker(k):
+        out = np.empty((H, W, 4), dtype=np.uint8)
+        start.wait()
+        for _ in range(40):
+            out[:] = 0
+            rc = lib.tr_read_rgba8_static(states[k]._ctx, out.ctypes.data, 1)  # (ctypes releases the GIL during the call)
+            if rc == 0:
+                results[k]["ok" if np.array_equal(out, wants[k]) else "bad"] += 1
+            elif rc == -7:  # TR_ERR_BUSY
+                results[k]["busy"] += 1
+            else:
+                results[k]["other"].append(rc)
+
+    try:
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for k, r in enumerate(results):
+            assert r["bad"] == 0 and not r["other"], (k, r)
+            assert r["ok"] > 0, (k, r)
+        # a refused call simply succeeds when made again
+        out = np.empty((H, W, 4), dtype=np.uint8)
+        assert lib.tr_read_rgba8_static(states[0]._ctx, out.ctypes.data, 1) == 0 and np.array_equal(out, wants[0])
+        print("static read, two contexts:", results)
+    finally:
+        for st in states:
+            st.close()

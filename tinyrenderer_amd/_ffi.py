@@ -20,6 +20,7 @@ TR_ERR = {
     -4: "TR_ERR_OOM",
     -5: "TR_ERR_UNSUPPORTED",
     -6: "TR_ERR_SIZE",
+    -7: "TR_ERR_BUSY",
 }
 TR_FLAG_TRI_TOO_LARGE = 1 << 0
 TR_FLAG_REF_PANIC_SPLIT = 1 << 1

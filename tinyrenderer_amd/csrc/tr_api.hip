@@ -483,6 +483,9 @@ constexpr size_t kStaticStagePixels = (size_t)3840 * 2160;
 __device__ __align__(256) uint32_t g_static_stage[kStaticStagePixels];
 uint32_t* g_static_stage_ptr[kMaxDevices];  // per device; nullptr until tr_create ran on it
 std::mutex g_static_stage_lock;
+// One call at a time per GPU: every context of a GPU shares that GPU's array, so a second call that arrives while one
+// is between its flip launch and the end of its copy is refused (TR_ERR_BUSY) instead of racing it.
+std::atomic_flag g_static_stage_busy[kMaxDevices];  // (static storage: clear)
 
 // (the caller has made `device` current)
 hipError_t init_static_stage(int device) {
@@ -824,7 +827,9 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
         return bail(TR_ERR_NO_DEVICE);
     }
     size_t npix = (size_t)width * height;
-    if (init_static_stage(device) != hipSuccess) return bail(TR_ERR_HIP);  // (device address of tr_read_rgba8_static's staging array)
+    // (device address of tr_read_rgba8_static's staging array, looked up once per device with that device current; a
+    // failure is that call's to report -- TR_ERR_UNSUPPORTED -- not a reason to refuse a context that may never use it)
+    (void)init_static_stage(device);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->planes, 2 * c->npix_all * sizeof(unsigned long long)) != hipSuccess) return bail(TR_ERR_OOM);
     c->depth = c->planes;
@@ -1409,10 +1414,6 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
     return TR_OK;
 }
 
-// Tile and row raster: a bin list that proved too small is grown and the resolve redone HERE (one read of the
-// status word, i.e. a host wait per resolve in those two modes), so that what tr_resolve leaves in the planes
-// is the frame -- a caller that consumes tr_device_ptr_rgba8 on the stream and clears without ever reading back
-// would otherwise get a frame that drew nothing, and the aborted frame's fill cursors would leak into the next.
 int tr_select_view(tr_context* c, int view) {
     if (!c) return TR_ERR_INVALID;
     if (view < 0 || view >= c->n_views) return fail(c, TR_ERR_INVALID, "tr_select_view: no such view in the current frame");
@@ -1423,7 +1424,20 @@ int tr_select_view(tr_context* c, int view) {
 // The reference renders one view per iteration of its loop (src/main.rs:57-116,272-273: clear_screen, camera,
 // render_mesh_component).  Here n_views iterations over ONE mesh are a single frame of n_views plane slices: one
 // setup launch over (view, triangle), one slot sequence, one depth pass, one winner pass, one shade launch.
+static int render_views_impl(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask);
 int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask) {
+    const int rc = render_views_impl(c, mesh, params, n_views, out_mask);
+    if (rc != TR_OK && c) {
+        // a batch that failed half way (capacity, upload, launch) must not read back as a resolved, empty frame: the
+        // context is left as tr_clear leaves it, and keeps the failure's text
+        std::string why;
+        try { why = c->err; } catch (...) {}
+        (void)tr_clear(c);
+        try { c->err = why; } catch (...) {}
+    }
+    return rc;
+}
+static int render_views_impl(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask) {
     if (!c || !mesh || !params) return TR_ERR_INVALID;
     if (c->max_views < 2) return fail(c, TR_ERR_INVALID, "tr_render_views needs a context made by tr_create_views");
     if (n_views < 1 || n_views > c->max_views) return fail(c, TR_ERR_SIZE, "tr_render_views: n_views outside [1, max_views]");
@@ -1516,6 +1530,10 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
     return tr_resolve(c, out_mask);
 }
 
+// Tile and row raster: a bin list that proved too small is grown and the resolve redone HERE (one read of the
+// status word, i.e. a host wait per resolve in those two modes), so that what tr_resolve leaves in the planes
+// is the frame -- a caller that consumes tr_device_ptr_rgba8 on the stream and clears without ever reading back
+// would otherwise get a frame that drew nothing, and the aborted frame's fill cursors would leak into the next.
 int tr_resolve(tr_context* c, uint32_t out_mask) {
     int rc = resolve_frame(c, out_mask, true);
     if (rc == TR_OK && c->mode != 0) rc = settle_bin_overflow(c);
@@ -1667,7 +1685,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         const bool views = c->max_views > 1;
         sa.view_blk_rows = c->blk_rows_per_view;
         sa.view_pix = (uint32_t)((size_t)c->W * c->H);
-        dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, c->blk_rows_per_view * (unsigned)(views ? c->n_views : 1));
+        dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, c->blk_rows_per_view, (unsigned)(views ? c->n_views : 1));
         sa.blk_y0 = 0;
         sa.blk_x0 = 0;
         sa.blocks_x = sgrid.x;
@@ -1705,7 +1723,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
                     else if (sa.blk_x0 > 0) { sa.blk_x0 -= 1; sgrid.x += 1; }
                 }
                 sa.launch_rows = sgrid.y;
-                if (views) sgrid.y *= (unsigned)c->n_views;  // (the same box in every slice of the batch)
+                // (the same box in every slice of the batch: the views are the grid's z)
             }
         } else {
             c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = c->W; c->paint_box.y1 = c->H;
@@ -1838,9 +1856,16 @@ int tr_read_rgba8_static(tr_context* c, uint8_t* out, int flip) {
             return fail(c, TR_ERR_UNSUPPORTED, "tr_read_rgba8_static: bin list overflow pending; tr_get_status_flags settles it (and may allocate)");
     }
     const uint32_t* src = c->rgba8 + (size_t)c->sel_view * npix;
+    struct Busy {  // (released on every way out)
+        std::atomic_flag* f = nullptr;
+        ~Busy() { if (f) f->clear(std::memory_order_release); }
+    } busy;
     if (flip) {
         uint32_t* stage = static_stage(c->device);
         if (!stage) return fail(c, TR_ERR_UNSUPPORTED, "tr_read_rgba8_static: no staging array on this device");
+        if (g_static_stage_busy[c->device].test_and_set(std::memory_order_acquire))
+            return fail(c, TR_ERR_BUSY, "tr_read_rgba8_static: another call is using this GPU's staging array (all contexts of a GPU share it); call again");
+        busy.f = &g_static_stage_busy[c->device];
         // every one of the W*H words copied below is written here first: the array's old contents
         // (the last call's image, of any size) never reach the caller
         hipLaunchKernelGGL(k_flip_rows, dim3(2048), dim3(256), 0, c->stream, src, stage, c->W, c->H);
@@ -1948,11 +1973,7 @@ int tr_set_band(tr_context* c, int y_lo, int y_hi) {
 
 int tr_set_colour_exact(tr_context* c, int exact) {
     if (!c) return TR_ERR_INVALID;
-    if ((exact != 0) != c->colour_exact) {
-        c->colour_exact = exact != 0;
-        // what is resolved was shaded the other way: the next read of the colour plane shades again
-        if (c->resolved) c->resolved_mask &= ~(uint32_t)(TR_OUT_RGBA8 | TR_OUT_RGBA_F64);
-    }
+    c->colour_exact = exact != 0;  // (from the next resolve on: what is resolved stays as it was shaded)
     return TR_OK;
 }
 

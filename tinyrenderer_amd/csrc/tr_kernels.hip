@@ -1563,7 +1563,8 @@ __global__ __launch_bounds__(64 * kMidWaves) void k_mid(RasterArgs a, uint8_t* h
             double* r = sRec[w][lane];
             r[0] = sl.ax; r[1] = sl.ay; r[2] = sl.az; r[3] = sl.dx; r[4] = sl.dy; r[5] = sl.dz;
             r[6] = 1.0 / (double)sl.hres;
-            cnt = sl.hres + 1u;  // (hres <= 65: the half's extent is at most 63 pixels)
+            cnt = sl.hres + 1u;  // (k_setup bounds res <= 63 and the half's estimated samples (mid_samples), not hres: a thin half may have hres in
+                                 // the thousands; the 32-bit prefix and the key's 18-bit j field hold it)
         }
         uint32_t inc = cnt;
 #pragma unroll
@@ -1881,8 +1882,9 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
     const int x = (int)bx * kShadeBW + (threadIdx.x & (kShadeBW - 1));
     // (a context that owns a band of rows launches the block rows of its band only: blk_y0 is the first of them)
     // (a batch of views launches rows [blk_y0, blk_y0 + launch_rows) of every view, one view after the other)
-    const uint32_t view = VIEWS ? blockIdx.y / a.launch_rows : 0u;
-    const uint32_t row = a.blk_y0 + (VIEWS ? blockIdx.y - view * a.launch_rows : blockIdx.y);
+    // (the view is the grid's z: rows x views may pass the 65 535 a grid dimension holds)
+    const uint32_t view = VIEWS ? blockIdx.z : 0u;
+    const uint32_t row = a.blk_y0 + blockIdx.y;
     const uint32_t by = (VIEWS ? view * a.view_blk_rows : 0u) + row;
     const int y = (int)row * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
