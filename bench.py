@@ -83,7 +83,7 @@ def secondary_bands(torch, dist, rank, world, device, frames=8, warm=12):
     mesh = st._mesh_handle(mc.mesh)
     on_gpu = world == 1 or dist.get_backend() == "nccl"
     bands = [sharding.band_rows(H, r, world) for r in range(world)]
-    per_frame, renders, full = [], [], None
+    per_frame, renders, gathers, full = [], [], [], None
     for it in range(warm + frames):
         y_lo, y_hi = bands[rank]
         if world > 1:
@@ -97,27 +97,33 @@ def secondary_bands(torch, dist, rank, world, device, frames=8, warm=12):
         t_render = (time.perf_counter() - t0) * 1e3
         assert rcs == (0, 0, 0, 0), rcs
         sharding.to_torch(st)
+        t1 = time.perf_counter()
         full = sharding.gather_bands(plane[y_lo:y_hi], H, dst=0, spans=bands)
         torch.cuda.synchronize()
+        t_gather = (time.perf_counter() - t1) * 1e3  # this rank's share of the one delivery gather (send, or all receives on rank 0)
         sharding.to_renderer(st)
         if world > 1:
             dist.barrier()
         t_frame = (time.perf_counter() - t0) * 1e3
-        times = [t_render]
+        times, gtimes = [t_render], [t_gather]
         if world > 1:
-            t = torch.tensor([t_render], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            t = torch.tensor([t_render, t_gather], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             out = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(out, t)
-            times = [float(x.item()) for x in out]
+            times = [float(x[0].item()) for x in out]
+            gtimes = [float(x[1].item()) for x in out]
         if it >= warm:
             per_frame.append(t_frame)
             renders.append(times)
+            gathers.append(gtimes)
         if world > 1:
             bands = sharding.rebalance(bands, times, H)
     rec = {"workload": f"african_head subdivided {levels}x ({draws[0][0].mesh.triangles.shape[0]} triangles) {W}x{H}, "
                        f"{world} tile-row band(s), RGBA8 gather to rank 0 (BASELINE.json configs[3])",
            "frames_per_s": 1e3 / float(np.median(per_frame)), "ms_per_frame": float(np.median(per_frame)),
-           "render_ms_per_rank_last_frame": [round(x, 3) for x in renders[-1]], "band_rows_last_frame": [hi - lo for lo, hi in bands]}
+           "render_ms_per_rank_last_frame": [round(x, 3) for x in renders[-1]], "band_rows_last_frame": [hi - lo for lo, hi in bands],
+           "gather_ms_per_rank_median": [round(float(np.median([g[r] for g in gathers])), 3) for r in range(world)],
+           "gather_bytes_per_rank_last_frame": [(hi - lo) * W * 4 for lo, hi in bands], "backend": dist.get_backend() if world > 1 else "none (one rank)"}
     if rank == 0 and levels == 6:
         import hashlib
 
@@ -163,6 +169,8 @@ def secondary_orbit(torch, dist, rank, world, device, n_total=4096):
     if rank == 0 and world > 1:
         recv = [torch.empty((batch, H, W), dtype=torch.int32, device="cuda" if on_gpu else "cpu") for _ in range(world)]
 
+    gather_s = [0.0, 0]
+
     def run(deliver):
         done, i = 0, 0
         while done < max_local:  # (every rank makes the same number of gather calls)
@@ -175,8 +183,11 @@ def secondary_orbit(torch, dist, rank, world, device, n_total=4096):
                     _ffi.check(s_._ctx, rc, "tr_render_views")
             if deliver and world > 1:
                 sharding.to_torch(s_)
+                tg = time.perf_counter()
                 src = planes[i % n_ctx] if on_gpu else planes[i % n_ctx].cpu()
                 dist.gather(src, recv, dst=0)
+                gather_s[0] += time.perf_counter() - tg  # (host time of the call: the collective itself is asynchronous on the stream)
+                gather_s[1] += 1
                 sharding.to_renderer(s_)
             done += batch
             i += 1
@@ -201,9 +212,65 @@ def secondary_orbit(torch, dist, rank, world, device, n_total=4096):
                        f"(tr_render_views) on {n_ctx} contexts (BASELINE.json configs[4])",
            "views_per_s_resident": n_total / t_res, "views_per_s_delivered_to_rank0": n_total / t_del,
            "fragments_last_batch_context0": frags}
+    rec["gather_bytes_per_batch_per_rank"] = batch * W * H * 4
+    rec["gather_call_ms_per_batch_this_rank"] = (gather_s[0] / gather_s[1] * 1e3) if gather_s[1] else None
+    if world > 1:
+        t = torch.tensor([rec["gather_call_ms_per_batch_this_rank"] or 0.0], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rec["gather_call_ms_per_batch_per_rank"] = [round(float(x.item()), 3) for x in allt]
+        rec["backend"] = dist.get_backend()
     for s_ in states:
         s_.close()
+    if rank == 0 and world == 1 and os.environ.get("TR_BENCH_NO_CPU_BASELINE") != "1":
+        rec["cpu_baseline"] = cpu_baseline_orbit(n_total)
     return rec
+
+
+def _orbit_cpu_worker(args):
+    """One process of the view-parallel CPU figure: the oracle on a block of views of the orbit (CPU only)."""
+    ks, n_total, W, H = args
+    import oracle_ffi as O
+    import scene_util as SU
+    from tinyrenderer_amd import scenes
+
+    mc = SU.component("diablo")
+    mc.transform.set_rotation((0.0, 0.0, 0.0))
+    st = O.OracleState(W, H)
+    tex, nm = O.OracleImage(mc.texture[::-1], flip=True), O.OracleImage(mc.normal_map[::-1], flip=True)
+    shaders = [scenes.shader_for(mc, W, H, eye=scenes.orbit_eye(k, n_total)) for k in ks]
+    t0 = time.perf_counter()
+    for sh in shaders:
+        st.clear_screen()
+        assert st.render_mesh_component(mc.mesh, sh, tex, nm) == 0
+    return time.perf_counter() - t0, len(ks)
+
+
+def cpu_baseline_orbit(n_total, W=1920, H=1080, views_per_proc=6):
+    """the N-process view-parallel CPU figure for configs[4] -- the oracle ('port' of the reference: the
+    Rust binary cannot be built here) on N processes, each rendering its own views of the orbit (the loop of
+    src/main.rs:57-116 with the view as the loop variable).  A bounded sample: N x views_per_proc views spread over the orbit."""
+    import multiprocessing as mp
+
+    n_proc = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)))  # (the box's CPU share: 16)
+    n_views = n_proc * views_per_proc
+    ks = [int(i * n_total / n_views) for i in range(n_views)]
+    blocks = [(ks[p::n_proc], n_total, W, H) for p in range(n_proc)]
+    ctx = mp.get_context("spawn")  # (never fork a process that has initialised the GPU)
+    with ctx.Pool(n_proc) as pool:
+        res = pool.map(_orbit_cpu_worker, blocks)
+    slowest = max(t for t, _ in res)
+    one = float(np.mean([t / n for t, n in res]))
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": n_views / slowest, "unit": "views/s", "cores": n_proc, "kind": "port",
+            "sample": f"{n_views} views spread over the {n_total}-view orbit at {W}x{H}, {views_per_proc} per process, {n_proc} processes "
+                      "(C++ restatement of the reference, oracle/, one thread each; clear + draw per view, no present); "
+                      "views / slowest process's render time",
+            "ms_per_view_one_core": one * 1e3, "cpu_model": cpu_model, "host_cpus": os.cpu_count()}
 
 
 def main():
