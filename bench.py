@@ -84,8 +84,10 @@ def secondary_bands(torch, dist, rank, world, device, frames=8, warm=12):
     on_gpu = world == 1 or dist.get_backend() == "nccl"
     bands = [sharding.band_rows(H, r, world) for r in range(world)]
     per_frame, renders, gathers, full = [], [], [], None
+    last_band, last_spans = bands[rank], list(bands)
     for it in range(warm + frames):
         y_lo, y_hi = bands[rank]
+        last_band, last_spans = bands[rank], list(bands)  # (the cut this frame is rendered and gathered with; re-cut below)
         if world > 1:
             dist.barrier()
         st.synchronize()
@@ -124,12 +126,26 @@ def secondary_bands(torch, dist, rank, world, device, frames=8, warm=12):
            "render_ms_per_rank_last_frame": [round(x, 3) for x in renders[-1]], "band_rows_last_frame": [hi - lo for lo, hi in bands],
            "gather_ms_per_rank_median": [round(float(np.median([g[r] for g in gathers])), 3) for r in range(world)],
            "gather_bytes_per_rank_last_frame": [(hi - lo) * W * 4 for lo, hi in bands], "backend": dist.get_backend() if world > 1 else "none (one rank)"}
-    if rank == 0 and levels == 6:
+    if levels == 6:
+        # the timed frames use the library's default (fused, +-1 LSB) colour arithmetic: one more frame over the same bands
+        # with the reference's arithmetic must hash to the oracle's digest, and the timed frame stay within 1 LSB of it
         import hashlib
 
-        want = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["c4_head_sub6_8k"]["rgba8"]
-        img = full.cpu().numpy().view(np.uint8).reshape(H, W, 4)[::-1]  # (the plane is not flipped)
-        rec["verified"] = hashlib.sha256(np.ascontiguousarray(img)).hexdigest() == want
+        fused = None if full is None else full.cpu().numpy().view(np.uint8).reshape(H, W, 4)[::-1].astype(np.int16)  # (the plane is not flipped)
+        st.set_colour_exact(True)
+        y_lo, y_hi = last_band
+        rcs = (lib.tr_clear(cx), lib.tr_set_band(cx, y_lo, y_hi), lib.tr_draw(cx, mesh, C.byref(params)), lib.tr_resolve(cx, _ffi.TR_OUT_RGBA8))
+        assert rcs == (0, 0, 0, 0), rcs
+        sharding.to_torch(st)
+        exact = sharding.gather_bands(plane[y_lo:y_hi], H, dst=0, spans=last_spans)
+        torch.cuda.synchronize()
+        sharding.to_renderer(st)
+        if rank == 0:
+            want = json.load(open(os.path.join(ROOT, "tests", "golden", "hashes.json")))["c4_head_sub6_8k"]["rgba8"]
+            img = exact.cpu().numpy().view(np.uint8).reshape(H, W, 4)[::-1]
+            lsb = int(np.abs(fused - img.astype(np.int16)).max())
+            rec["max_colour_lsb_vs_exact"] = lsb
+            rec["verified"] = hashlib.sha256(np.ascontiguousarray(img)).hexdigest() == want and lsb <= 1
     st.close()
     return rec
 
