@@ -53,6 +53,41 @@ def diablo_1080p_frame1():
     return W, H, [(mc, scenes.shader_for(mc, W, H))]
 
 
+def config1_ext_scene(W=1024, H=1024, M=1024):
+    """configs[1]: diablo3_pose with normal + specular maps and a shadow-map pass at 1024x1024.  Phong, the specular
+    map and the shadow pass are EXTENSION shaders (the reference has one shader pair and loads no *_spec.png):
+    defined by include/tinyrenderer_hip.h, restated on the CPU in oracle/ -- parity unpinned by construction.
+    Returns (mesh component, camera shader, light shader, camera-viewport -> light-viewport matrix)."""
+    from tinyrenderer_amd.model_renderer import shadow_from_view
+
+    mc = SU.component("diablo")
+    mc.parent = None
+    mc.transform.set_rotation((0.0, 0.0, 0.0))
+    light_eye = (1.2, 0.9, 1.6)
+    sh = scenes.shader_for(mc, W, H)
+    sh.camera_pos = light_eye  # the shader's light direction (main.rs:249-251 uses the camera's position)
+    light_sh = scenes.shader_for(mc, M, M, eye=light_eye)
+    return mc, sh, light_sh, shadow_from_view(sh, W, H, light_sh, M, M)
+
+
+def config1_ext(shadow, m):
+    """The ShadeExt of configs[1] over a shadow source (a HostShadow for the CPU statement, a ShadowMap on the GPU)."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd.model_renderer import ShadeExt
+
+    return ShadeExt(model=_ffi.TR_SHADE_PHONG, specular_map=scenes.load_specular("diablo"), specular_strength=0.6,
+                    shadow=shadow, shadow_from_view=m, shadow_bias=0.01, shadow_dim=0.3)
+
+
+def config1_ext_oracle(oracle, W=1024, H=1024, M=1024):
+    """The CPU statement's frame of configs[1]: (planes of the camera pass, z plane of the light pass)."""
+    from tinyrenderer_amd.model_renderer import HostShadow
+
+    mc, sh, light_sh, m = config1_ext_scene(W, H, M)
+    zl = SU.oracle_render(oracle, M, M, [(mc, light_sh)])["z"]
+    return SU.oracle_render(oracle, W, H, [(mc, sh, config1_ext(HostShadow(zl), m))]), zl
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a)).hexdigest()
 

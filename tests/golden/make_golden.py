@@ -66,8 +66,27 @@ def big_cases():
     return out
 
 
+def ext_case():
+    """configs[1] at full size with the EXTENSION shaders (Phong + specular map + shadow map): digests of the build's own
+    CPU statement (oracle/), not of anything the reference computes.  `python tests/golden/make_golden.py --ext`."""
+    import big_cases as B
+
+    o, zl = B.config1_ext_oracle(oracle_ffi)
+    d = B.digest_row_major(o["z"].T, o["key"].T, o["present"], o["counters"])
+    d["light_z"] = B.sha(np.ascontiguousarray(zl.T).view(np.uint64))
+    d["note"] = "extension shaders: the build's own CPU statement, parity with the reference unpinned by construction"
+    return {"c2x_diablo_1024_phong_spec_shadow": d}
+
+
 def main():
     path = os.path.join(HERE, "hashes.json")
+    if "--ext" in sys.argv:
+        hashes = json.load(open(path))
+        hashes.update(ext_case())
+        with open(path, "w") as fh:
+            json.dump(hashes, fh, indent=1, sort_keys=True)
+        print(json.dumps({k: v for k, v in hashes.items() if k.startswith("c2x_")}, indent=1))
+        return
     if "--big" in sys.argv:  # (kept apart: the small cases take seconds, these a minute)
         hashes = json.load(open(path))
         hashes.update(big_cases())
@@ -75,7 +94,7 @@ def main():
             json.dump(hashes, fh, indent=1, sort_keys=True)
         print(json.dumps({k: v for k, v in hashes.items() if k.startswith(("c3_", "c4_", "c5_"))}, indent=1))
         return
-    hashes = {k: v for k, v in json.load(open(path)).items() if k.startswith(("c3_", "c4_", "c5_"))} if os.path.exists(path) else {}
+    hashes = {k: v for k, v in json.load(open(path)).items() if k.startswith(("c2x_", "c3_", "c4_", "c5_"))} if os.path.exists(path) else {}
     for name, (_, W, H, full) in CASES.items():
         o = render(name)
         hashes[name] = digest(o)

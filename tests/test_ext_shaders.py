@@ -129,6 +129,46 @@ def test_gpu_diablo_phong_specular_shadow_map_config1():
 
 
 @pytest.mark.gpu
+def test_gpu_config1_full_size_1024_phong_specular_shadow():
+    """BASELINE.json configs[1] at FULL size: diablo3_pose 1024x1024, normal + specular maps, 1024x1024 shadow map, light
+    pass + camera pass.  EXTENSION shaders: the yardstick is the build's own CPU statement (oracle/), directly and through
+    the digests it left in tests/golden/hashes.json (make_golden.py --ext).  Visibility and the light's depth plane bit
+    for bit, colour within 1 LSB (pow() differs between libm and the device library in the last bits)."""
+    import json
+    import os
+
+    import big_cases as B
+
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hashes.json")))["c2x_diablo_1024_phong_spec_shadow"]
+    Wf = Hf = M = 1024
+    mc, sh, light_sh, m = B.config1_ext_scene(Wf, Hf, M)
+    light = ModelRendererState(M, M)
+    try:
+        clear_screen(light)
+        render_mesh_component(light, mc, light_sh)  # (not resolved: the snapshot resolves for depth only)
+        sm = ShadowMap(light, keep_host_copy=True)
+    finally:
+        light.close()
+    try:
+        assert B.sha(np.ascontiguousarray(sm.z_reference().T).view(np.uint64)) == want["light_z"]
+        g = SU.gpu_render(Wf, Hf, [(mc, sh, B.config1_ext(sm, m))])
+    finally:
+        sm.close()
+    assert g["flags"] == 0
+    assert B.sha(np.ascontiguousarray(g["key"].T)) == want["key"] and int((g["key"] != B.NONE_KEY).sum()) == want["covered"]
+    assert B.sha(np.ascontiguousarray(g["z"].T).view(np.uint64)) == want["z"]
+    for k in ("samples", "fragments", "scanlines"):
+        assert g["counters"][k] == want["counters"][k]
+    o, _ = B.config1_ext_oracle(oracle_ffi, Wf, Hf, M)
+    assert B.sha(o["present"]) == want["rgba8"]  # (the CPU statement still says what it said when the digest was made)
+    r = SU.assert_parity(o, g, color_lsb=1)
+    ref = SU.oracle_render(oracle_ffi, Wf, Hf, [(mc, sh)])
+    changed = (np.abs(o["present"].astype(int) - ref["present"].astype(int)).max(axis=2) > 8).sum()
+    assert changed > 5000, "specular term and shadow must change the frame visibly"
+    print("configs[1] 1024x1024 ext:", r, "pixels changed by the extensions:", int(changed))
+
+
+@pytest.mark.gpu
 def test_gpu_mixed_frame_reference_draw_stays_exact():
     """A frame with one extension draw and one reference draw: the latter's pixels carry the
     reference's f64 colours bit for bit."""
