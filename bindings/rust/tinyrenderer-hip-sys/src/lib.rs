@@ -115,6 +115,8 @@ extern "C" {
     pub fn tr_create_views(device: c_int, width: c_int, height: c_int, max_views: c_int, out_ctx: *mut *mut tr_context) -> c_int;
     pub fn tr_render_views(ctx: *mut tr_context, mesh: *const tr_mesh, params: *const tr_draw_params, n_views: c_int, out_mask: u32) -> c_int;
     pub fn tr_select_view(ctx: *mut tr_context, view: c_int) -> c_int;
+    // the loop's own scene, several meshes per iteration (main.rs:272-273): params[v * n_meshes + m]
+    pub fn tr_render_views_multi(ctx: *mut tr_context, n_meshes: c_int, meshes: *const *const tr_mesh, params: *const tr_draw_params, n_views: c_int, out_mask: u32) -> c_int;
     // multi-GPU bands, strategy, plumbing
     pub fn tr_set_band(ctx: *mut tr_context, y_lo: c_int, y_hi: c_int) -> c_int;
     pub fn tr_set_raster_mode(ctx: *mut tr_context, mode: c_int) -> c_int;

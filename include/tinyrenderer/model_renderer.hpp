@@ -216,6 +216,22 @@ inline void render_views(ModelRendererState& state, const MeshComponent& mesh_co
                 "tr_render_views");
 }
 
+// The same for the loop's own scene of several meshes per iteration (main.rs:272-273: the head, then the eye parented to
+// it): shaders[v][m] is mesh m's shader under view v (its model_view holds local_to_world_matrix with the parents folded
+// in, mod.rs:67-84); one batch (tr_render_views_multi), one slice per view.
+inline void render_views_multi(ModelRendererState& state, const std::vector<const MeshComponent*>& mesh_components,
+                               const std::vector<std::vector<BuiltinShader>>& shaders, uint32_t out_mask = TR_OUT_RGBA8) {
+    std::vector<tr_draw_params> params;
+    std::vector<const tr_mesh*> meshes;
+    for (const MeshComponent* mc : mesh_components) meshes.push_back(state.mesh_handle(mc->mesh));
+    for (const auto& row : shaders) {
+        if (row.size() != mesh_components.size()) throw RendererError("render_views_multi: one shader per mesh and view");
+        for (size_t m = 0; m < row.size(); ++m) params.push_back(make_draw_params(state, *mesh_components[m], row[m]));
+    }
+    state.check(tr_render_views_multi(state.context(), (int)meshes.size(), meshes.data(), params.data(), (int)shaders.size(), out_mask),
+                "tr_render_views_multi");
+}
+
 inline tr_draw_params make_draw_params(ModelRendererState& state, const MeshComponent& mesh_component, const BuiltinShader& shader) {
     tr_draw_params p{};
     const Matrix4 pmv = shader.perspective_matrix * shader.model_view_matrix;  // main.rs:152-153

@@ -232,10 +232,18 @@ int tr_get_status_flags(tr_context* ctx, uint32_t* out_flags);
  * tr_read_rgba8_static and tr_device_ptr_rgba8 refer to (view 0 after tr_create_views); the slices are contiguous
  * in view order, so tr_device_ptr_rgba8 of view 0 addresses all n_views images.  tr_get_counters sums over the
  * batch.  A context made by tr_create_views (max_views in [2, 4096], W * H * max_views < 2^31) renders through
- * tr_render_views only (tr_draw: TR_ERR_INVALID) and uses the global raster; no bands, no extension shaders. */
+ * tr_render_views / tr_render_views_multi only (tr_draw: TR_ERR_INVALID) and uses the global raster; no bands, no extension shaders. */
 int tr_create_views(int device, int width, int height, int max_views, tr_context** out_ctx);
 int tr_render_views(tr_context* ctx, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask);
 int tr_select_view(tr_context* ctx, int view);
+/* The same for the reference's own scene: its loop draws SEVERAL meshes per iteration -- the head and the eye parented
+ * to it (src/main.rs:272-273; the parent fold of src/model_renderer/mod.rs:67-84 is in each draw's matrices).
+ * meshes[0 .. n_meshes) (1 to 4) are drawn in that order in every view; params[v * n_meshes + m] is what tr_draw takes
+ * for mesh m under view v.  Per view the results are those of tr_clear + n_meshes x tr_draw + tr_resolve: tri_seq
+ * continues across the meshes as in tr_draw, and over the batch view v's triangle k of mesh m is
+ * v * T + (triangles of meshes before m) + k with T the triangles of all meshes.  n_views x n_meshes <= 4096. */
+int tr_render_views_multi(tr_context* ctx, int n_meshes, const tr_mesh* const* meshes, const tr_draw_params* params,
+                          int n_views, uint32_t out_mask);
 
 /* Multi-GPU band sharding (no reference analogue; exact because a pixel's result is a pure min
  * over the samples landing on it): restrict this context to pixel rows [y_lo, y_hi), whole

@@ -223,3 +223,65 @@ def test_more_block_rows_times_views_than_a_grid_dimension_holds(oracle):
                     assert np.array_equal(_local_key(st.winner_keys(), v, mc.mesh.triangles.shape[0]), o["key"]), v
     finally:
         st.close()
+
+
+def test_reference_loop_head_and_parented_eye_as_one_batch(oracle):
+    """The reference's own scene (src/main.rs:57-116,272-273): every iteration turns the head a little further
+    (`0.025 * time`) and draws it and then the eye whose parent it is (mod.rs:67-84).  Six iterations as ONE batch of
+    two meshes (tr_render_views_multi), view by view against the oracle's two-draw frame: depth, winner keys (tri_seq
+    continues across the two meshes), triangle ids, f64 colour, presented image, counters."""
+    from tinyrenderer_amd.model_renderer import render_views_multi
+
+    W, H = 320, 180
+    head, eye = SU.component("head"), SU.component("eye_inner")
+    eye.parent = head
+    n_head, n_eye = head.mesh.triangles.shape[0], eye.mesh.triangles.shape[0]
+    T = n_head + n_eye
+    times = (1, 2, 7, 40, 63, 100)
+    shaders = []
+    for t in times:
+        head.transform.set_rotation((0.025 * t, 0.0, 0.0))
+        shaders.append([scenes.shader_for(head, W, H), scenes.shader_for(eye, W, H)])  # (matrices are captured now)
+    st = ModelRendererState(W, H, max_views=8)
+    try:
+        for mask in (MASK, _ffi.TR_OUT_RGBA8):
+            render_views_multi(st, [head, eye], shaders, mask)
+            assert st.status_flags() == 0
+            total = {"samples": 0, "fragments": 0, "scanlines": 0, "covered": 0}
+            eye_won = 0
+            for v, (sh_head, sh_eye) in enumerate(shaders):
+                o = SU.oracle_render(oracle, W, H, [(head, sh_head), (eye, sh_eye)])
+                st.select_view(v)
+                SU.check_present(st, o["present"], f"view {v}")
+                if mask == MASK:
+                    st.resolve(MASK)  # (check_present left an RGBA8-only resolve behind)
+                    z = st.z_buffer[..., 0]
+                    assert ((o["z"].view(np.uint64) == z.view(np.uint64)) | (np.isnan(o["z"]) & np.isnan(z))).all(), v
+                    assert np.array_equal(_local_key(st.winner_keys(), v, T), o["key"]), f"view {v}: winner keys"
+                    tri = st.triangle_ids().astype(np.int64)
+                    tri[tri == 0xFFFFFFFF] = -1
+                    assert np.array_equal(np.where(tri >= 0, tri - v * T, -1), o["seq"]), f"view {v}: triangle ids"
+                    fb = st.frame_buffer
+                    assert ((fb.view(np.uint64) == o["fb"].view(np.uint64)) | (np.isnan(fb) & np.isnan(o["fb"]))).all(), v
+                    eye_won += int((o["seq"] >= n_head).sum())
+                for k in ("samples", "fragments", "scanlines"):
+                    total[k] += o["counters"][k]
+                total["covered"] += int((o["key"] != B.NONE_KEY).sum())
+            c = st.counters()
+            assert (c["samples"], c["fragments"], c["scanlines"], c["covered_pixels"]) == \
+                (total["samples"], total["fragments"], total["scanlines"], total["covered"])
+            assert c["triangles"] == T * len(shaders)
+            if mask == MASK:
+                assert eye_won > 0, "no eye pixel won in any view: the second mesh was not exercised"
+        # a one-mesh batch on the same context afterwards: nothing of the two-mesh batch may show through
+        head.transform.set_rotation((0.3, 0.0, 0.0))
+        one = [scenes.shader_for(head, W, H)]
+        render_views(st, head, one, _ffi.TR_OUT_RGBA8)
+        st.select_view(0)
+        SU.check_present(st, SU.oracle_render(oracle, W, H, [(head, one[0])])["present"], "one mesh after two")
+        with pytest.raises(_ffi.TrError):
+            render_views_multi(st, [head] * 5, [[one[0]] * 5])  # more than four meshes
+    finally:
+        eye.parent = None
+        head.transform.set_rotation((0.025, 0.0, 0.0))
+        st.close()

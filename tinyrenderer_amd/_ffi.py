@@ -47,7 +47,7 @@ EXPORTS = [
     "tr_obj_normals", "tr_obj_indices", "tr_obj_free", "tr_image_load_rgba8", "tr_image_size", "tr_image_data",
     "tr_image_free", "tr_load_error", "tr_image_write_png", "tr_selftest_arithmetic",
     "tr_draw_ext", "tr_shadow_map_create", "tr_shadow_map_update", "tr_shadow_map_destroy", "tr_host_alloc", "tr_host_free",
-    "tr_read_rgba8_static", "tr_create_views", "tr_render_views", "tr_select_view", "tr_set_colour_exact",
+    "tr_read_rgba8_static", "tr_create_views", "tr_render_views", "tr_select_view", "tr_set_colour_exact", "tr_render_views_multi",
 ]
 
 
@@ -117,6 +117,7 @@ def load():
         "tr_create_views": (i32, [i32, i32, i32, i32, C.POINTER(vp)]),
         "tr_render_views": (i32, [vp, vp, C.POINTER(DrawParams), i32, u32]),
         "tr_select_view": (i32, [vp, i32]),
+        "tr_render_views_multi": (i32, [vp, i32, C.POINTER(vp), C.POINTER(DrawParams), i32, u32]),
         "tr_get_counters": (i32, [vp, C.POINTER(C.c_uint64)]),
         "tr_get_status_flags": (i32, [vp, C.POINTER(u32)]),
         "tr_synchronize": (i32, [vp]),

@@ -84,7 +84,9 @@ struct tr_context {
     uint32_t view_tris = 0;          // triangles per view of the current batch (0: the frame is not a batch)
     size_t npix_all = 0;             // W * H * max_views
     uint32_t blk_per_view = 0, blk_rows_per_view = 0;
-    ViewDev* view_table = nullptr;   // device, max_views entries
+    ViewDev* view_table = nullptr;   // device, view_cap entries (one per (view, mesh) of a batch)
+    size_t view_cap = 0;
+    uint32_t view_meshes = 1;        // meshes (draws) per view of the current batch
     ViewDev* view_stage[2] = {nullptr, nullptr};  // page-locked host copies, used in turn
     hipEvent_t view_ev[2] = {nullptr, nullptr};   // "the upload from view_stage[i] has completed"
     int view_turn = 0;
@@ -318,6 +320,23 @@ int ensure_tri_capacity(tr_context* c, size_t need) {
         TR_HIP(c, hipMalloc(&c->tile_sum, tiles * sizeof(unsigned long long)));
         c->tile_cap = tiles;
     }
+    return TR_OK;
+}
+
+// The per-(view, mesh) table of a batch of views and its two page-locked staging copies.
+int ensure_view_capacity(tr_context* c, size_t need) {
+    if (need <= c->view_cap) return TR_OK;
+    if (c->stream) TR_HIP(c, hipStreamSynchronize(c->stream));  // (an upload from the old staging copies may be in flight)
+    (void)hipFree(c->view_table);
+    c->view_table = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        if (c->view_stage[i]) (void)hipHostFree(c->view_stage[i]);
+        c->view_stage[i] = nullptr;
+    }
+    c->view_cap = 0;
+    TR_HIP(c, hipMalloc(&c->view_table, need * sizeof(ViewDev)));
+    for (int i = 0; i < 2; ++i) TR_HIP(c, hipHostMalloc((void**)&c->view_stage[i], need * sizeof(ViewDev), hipHostMallocDefault));
+    c->view_cap = need;
     return TR_OK;
 }
 
@@ -836,11 +855,9 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     c->wkey = c->planes + c->npix_all;
     if (hipMalloc(&c->rgba8, c->npix_all * sizeof(uint32_t)) != hipSuccess) return bail(TR_ERR_OOM);
     if (max_views > 1) {
-        if (hipMalloc(&c->view_table, (size_t)max_views * sizeof(ViewDev)) != hipSuccess) return bail(TR_ERR_OOM);
-        for (int i = 0; i < 2; ++i) {
-            if (hipHostMalloc((void**)&c->view_stage[i], (size_t)max_views * sizeof(ViewDev), hipHostMallocDefault) != hipSuccess) return bail(TR_ERR_OOM);
+        for (int i = 0; i < 2; ++i)
             if (hipEventCreateWithFlags(&c->view_ev[i], hipEventDisableTiming) != hipSuccess) return bail(TR_ERR_HIP);
-        }
+        if (ensure_view_capacity(c, (size_t)max_views) != TR_OK) return bail(TR_ERR_OOM);
     }
     (void)npix;
     if (hipMalloc(&c->draw_table, c->draw_cap * sizeof(DrawDev)) != hipSuccess) return bail(TR_ERR_OOM);
@@ -987,6 +1004,7 @@ int tr_clear(tr_context* c) {
     c->split_any = false;
     c->frame_tiled = false;
     c->view_tris = 0;
+    c->view_meshes = 1;
     c->n_views = c->max_views;  // (an empty frame resolves every slice)
     return TR_OK;
 }
@@ -1424,9 +1442,9 @@ int tr_select_view(tr_context* c, int view) {
 // The reference renders one view per iteration of its loop (src/main.rs:57-116,272-273: clear_screen, camera,
 // render_mesh_component).  Here n_views iterations over ONE mesh are a single frame of n_views plane slices: one
 // setup launch over (view, triangle), one slot sequence, one depth pass, one winner pass, one shade launch.
-static int render_views_impl(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask);
-int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask) {
-    const int rc = render_views_impl(c, mesh, params, n_views, out_mask);
+static int render_views_impl(tr_context* c, int n_meshes, const tr_mesh* const* meshes, const tr_draw_params* params, int n_views, uint32_t out_mask);
+static int render_views_guarded(tr_context* c, int n_meshes, const tr_mesh* const* meshes, const tr_draw_params* params, int n_views, uint32_t out_mask) {
+    const int rc = render_views_impl(c, n_meshes, meshes, params, n_views, out_mask);
     if (rc != TR_OK && c) {
         // a batch that failed half way (capacity, upload, launch) must not read back as a resolved, empty frame: the
         // context is left as tr_clear leaves it, and keeps the failure's text
@@ -1437,46 +1455,65 @@ int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* pa
     }
     return rc;
 }
-static int render_views_impl(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask) {
-    if (!c || !mesh || !params) return TR_ERR_INVALID;
+int tr_render_views(tr_context* c, const tr_mesh* mesh, const tr_draw_params* params, int n_views, uint32_t out_mask) {
+    return render_views_guarded(c, 1, &mesh, params, n_views, out_mask);
+}
+int tr_render_views_multi(tr_context* c, int n_meshes, const tr_mesh* const* meshes, const tr_draw_params* params, int n_views, uint32_t out_mask) {
+    return render_views_guarded(c, n_meshes, meshes, params, n_views, out_mask);
+}
+static int render_views_impl(tr_context* c, int n_meshes, const tr_mesh* const* meshes, const tr_draw_params* params, int n_views, uint32_t out_mask) {
+    if (!c || !meshes || !params) return TR_ERR_INVALID;
     if (c->max_views < 2) return fail(c, TR_ERR_INVALID, "tr_render_views needs a context made by tr_create_views");
     if (n_views < 1 || n_views > c->max_views) return fail(c, TR_ERR_SIZE, "tr_render_views: n_views outside [1, max_views]");
+    if (n_meshes < 1 || n_meshes > kMaxBatchMeshes) return fail(c, TR_ERR_SIZE, "tr_render_views_multi: 1 to 4 meshes per batch");
+    if ((uint64_t)n_views * (uint64_t)n_meshes > (uint64_t)c->draw_cap) return fail(c, TR_ERR_SIZE, "more than 4096 draws (views x meshes) in one batch");
     if (c->mode != 0) return fail(c, TR_ERR_UNSUPPORTED, "tr_render_views uses the global raster");
-    const uint64_t total = (uint64_t)n_views * (uint64_t)mesh->n_tris;
+    uint64_t per_view = 0;
+    for (int m = 0; m < n_meshes; ++m) {
+        if (!meshes[m]) return fail(c, TR_ERR_INVALID, "null mesh");
+        per_view += (uint64_t)meshes[m]->n_tris;
+    }
+    const uint64_t total = (uint64_t)n_views * per_view;
     if (total > (uint64_t)kTriSeqMax) return fail(c, TR_ERR_SIZE, "more than 2^28-1 triangles in one batch of views");
-    for (int v = 0; v < n_views; ++v)
-        if (mesh->any_uv && (!params[v].diffuse || (params[v].use_normal_map && !params[v].normal_map)))
+    const size_t n_draws = (size_t)n_views * (size_t)n_meshes;
+    for (size_t d = 0; d < n_draws; ++d)
+        if (meshes[d % (size_t)n_meshes]->any_uv && (!params[d].diffuse || (params[d].use_normal_map && !params[d].normal_map)))
             return fail(c, TR_ERR_INVALID, "mesh has texture coordinates but a texture is missing");
     int rc = tr_clear(c);
     if (rc != TR_OK) return rc;
-    c->n_views = n_views;
-    if (c->sel_view >= n_views) c->sel_view = 0;
-    for (int v = 0; v < n_views; ++v)
-        for (const tr_texture* t : {params[v].diffuse, params[v].normal_map})
-            if (t && std::find(c->frame_textures.begin(), c->frame_textures.end(), t) == c->frame_textures.end()) {
-                try { c->frame_textures.push_back(t); }
-                catch (...) { return fail(c, TR_ERR_OOM, "texture list"); }
-            }
-    c->draw_count = (uint32_t)n_views;
-    if (mesh->n_tris == 0) return tr_resolve(c, out_mask);
+    if (per_view == 0) {  // nothing to draw: every slice of the batch is background
+        c->n_views = n_views;
+        if (c->sel_view >= n_views) c->sel_view = 0;
+        c->draw_count = (uint32_t)n_draws;
+        return tr_resolve(c, out_mask);
+    }
     rc = ensure_tri_capacity(c, (size_t)total);
     if (rc != TR_OK) return rc;
     rc = grow_records_for(c, total);
     if (rc != TR_OK) return rc;
-    // the views' constants: written into one of two page-locked buffers (the copy from the other may still be
+    rc = ensure_view_capacity(c, n_draws);
+    if (rc != TR_OK) return rc;
+    for (size_t d = 0; d < n_draws; ++d)
+        for (const tr_texture* t : {params[d].diffuse, params[d].normal_map})
+            if (t && std::find(c->frame_textures.begin(), c->frame_textures.end(), t) == c->frame_textures.end()) {
+                try { c->frame_textures.push_back(t); }
+                catch (...) { return fail(c, TR_ERR_OOM, "texture list"); }
+            }
+    // the (view, mesh) constants: written into one of two page-locked buffers (the copy from the other may still be
     // in flight when batches are issued back to back), uploaded on the stream
     const int turn = c->view_turn;
     c->view_turn ^= 1;
     TR_HIP(c, hipEventSynchronize(c->view_ev[turn]));
     ViewDev* stage = c->view_stage[turn];
-    for (int v = 0; v < n_views; ++v) {
-        c->frame_box.add(draw_pix_box(c, mesh, params[v].pmv));
-        std::memcpy(stage[v].pmv.m, params[v].pmv, sizeof(stage[v].pmv.m));
-        std::memcpy(stage[v].nmat.m, params[v].normal_mat, sizeof(stage[v].nmat.m));
-        fill_draw_dev(stage[v].draw, &params[v]);
-        stage[v].z_split = c->depth_split ? split_depth(c, mesh, params[v].pmv) : std::nan("");
+    for (size_t d = 0; d < n_draws; ++d) {
+        const tr_mesh* mesh = meshes[d % (size_t)n_meshes];
+        c->frame_box.add(draw_pix_box(c, mesh, params[d].pmv));
+        std::memcpy(stage[d].pmv.m, params[d].pmv, sizeof(stage[d].pmv.m));
+        std::memcpy(stage[d].nmat.m, params[d].normal_mat, sizeof(stage[d].nmat.m));
+        fill_draw_dev(stage[d].draw, &params[d]);
+        stage[d].z_split = c->depth_split ? split_depth(c, mesh, params[d].pmv) : std::nan("");
     }
-    TR_HIP(c, hipMemcpyAsync(c->view_table, stage, (size_t)n_views * sizeof(ViewDev), hipMemcpyHostToDevice, c->stream));
+    TR_HIP(c, hipMemcpyAsync(c->view_table, stage, n_draws * sizeof(ViewDev), hipMemcpyHostToDevice, c->stream));
     TR_HIP(c, hipEventRecord(c->view_ev[turn], c->stream));
     c->draw0 = stage[0].draw;
     const uint32_t n_halves = 2u * (uint32_t)total;
@@ -1484,21 +1521,30 @@ static int render_views_impl(tr_context* c, const tr_mesh* mesh, const tr_draw_p
         ProfScope ps(c, ST_SETUP);
         SetupArgs sa;
         std::memset(&sa, 0, sizeof(sa));
+        const tr_mesh* mesh = meshes[0];
         sa.idx = mesh->idx; sa.pos = mesh->pos; sa.uvw = mesh->uvw; sa.nrm = mesh->nrm;
-        sa.n_pos = (int)mesh->n_pos; sa.n_nrm = (int)mesh->n_nrm; sa.n_tris = (int)mesh->n_tris;
+        sa.n_pos = (int)mesh->n_pos; sa.n_nrm = (int)mesh->n_nrm; sa.n_tris = (int)per_view;
+        sa.n_meshes = (uint32_t)n_meshes;
+        uint64_t off = 0;
+        for (int m = 0; m < n_meshes; ++m) {
+            sa.mesh_off[m] = (uint32_t)off;
+            off += (uint64_t)meshes[m]->n_tris;
+            sa.m_idx[m] = meshes[m]->idx; sa.m_pos[m] = meshes[m]->pos; sa.m_nrm[m] = meshes[m]->nrm; sa.m_uvw[m] = meshes[m]->uvw;
+        }
+        for (int m = n_meshes; m <= kMaxBatchMeshes; ++m) sa.mesh_off[m] = (uint32_t)off;
         sa.tri_base = 0; sa.draw = 0; sa.W = c->W; sa.H = c->H;
         sa.vpm = viewport_matrix(c->W, c->H);
         sa.rast = c->rast; sa.shade = c->shade; sa.half_cnt = c->half_cnt; sa.flags = c->flags;
         sa.tile_cnt = c->tile_cnt; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y; sa.tw_shift = c->tw_shift; sa.th_shift = c->th_shift;
         sa.small_flag = c->small_flag; sa.small_grp = c->small_grp;
         sa.y_lo = 0; sa.y_hi = c->H; sa.mode = 1;
-        if (c->small_path && (uint64_t)mesh->n_tris >= (uint64_t)c->small_draw_tris) {
+        if (c->small_path && per_view >= (uint64_t)c->small_draw_tris) {
             sa.mode |= 4;  // triangles of a few pixels go to k_small and own no slots
             sa.small_res = c->small_res;
             c->small_any = true;
         }
         sa.mid_samples = c->mid_samples;
-        if (use_mid_path(c, (uint64_t)mesh->n_tris, total)) {
+        if (use_mid_path(c, per_view, total)) {
             sa.mode |= 16;  // triangles of up to 64 scanlines per half and a few hundred samples: one wave per half (k_mid)
             c->mid_any = true;
         }
@@ -1511,7 +1557,12 @@ static int render_views_impl(tr_context* c, const tr_mesh* mesh, const tr_draw_p
         rc = launch_scan(c, 0u, n_halves);
         if (rc != TR_OK) return rc;
     }
-    c->view_tris = (uint32_t)mesh->n_tris;
+    // (the frame's bookkeeping only now: everything that can fail before a sample is drawn has succeeded)
+    c->n_views = n_views;
+    if (c->sel_view >= n_views) c->sel_view = 0;
+    c->draw_count = (uint32_t)n_draws;
+    c->view_meshes = (uint32_t)n_meshes;
+    c->view_tris = (uint32_t)per_view;
     c->tri_total = (uint32_t)total;
     {
         ProfScope ps(c, ST_DEPTH);
@@ -1684,6 +1735,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         sa.ext = c->ext_table;
         const bool views = c->max_views > 1;
         sa.view_blk_rows = c->blk_rows_per_view;
+        sa.view_meshes = c->view_meshes;
         sa.view_pix = (uint32_t)((size_t)c->W * c->H);
         dim3 sgrid((c->W + kShadeBW - 1) / kShadeBW, c->blk_rows_per_view, (unsigned)(views ? c->n_views : 1));
         sa.blk_y0 = 0;

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_transform(const double* __restrict__ po
 }
 
 // ================================================================ (2) setup
+constexpr int kMaxBatchMeshes = 4;  // meshes per batch of views (tr_render_views_multi)
 struct SetupArgs {
     const uint32_t* idx;   // 9 per triangle
     const double* pos;     // raw positions (face-normal fallback)
@@ -87,6 +88,16 @@ struct SetupArgs {
                            // or nullptr; a context that owns a band drops whole clusters that project outside its rows
     double z_split;        // viewport z of the mesh box's centre, or NaN: triangles whose centroid is farther get kTriFar
     uint8_t* cull;         // per cluster of this draw: 1 = misses the band (written by k_cull_clusters), or nullptr
+    // batched views of SEVERAL meshes (tr_render_views_multi: the reference's loop draws its head and the eye parented to
+    // it every iteration, main.rs:272-273): a view's triangles are those of mesh 0, then mesh 1, ... (n_tris = their sum);
+    // triangle kv of a view belongs to the mesh m with mesh_off[m] <= kv < mesh_off[m + 1]; views[view * n_meshes + m]
+    // holds that draw's matrices and constants, its draw-table entry is draw + view * n_meshes + m
+    uint32_t n_meshes;
+    uint32_t mesh_off[kMaxBatchMeshes + 1];
+    const uint32_t* m_idx[kMaxBatchMeshes];
+    const double* m_pos[kMaxBatchMeshes];
+    const double* m_nrm[kMaxBatchMeshes];
+    const double* m_uvw[kMaxBatchMeshes];
 };
 
 __device__ __forceinline__ void scan_in_block(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* off,
@@ -147,11 +158,23 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
         const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
         if (g >= a.n_views * (uint32_t)a.n_tris) return;
         const uint32_t view = g / (uint32_t)a.n_tris;
-        const int kv = (int)(g - view * (uint32_t)a.n_tris);
-        const ViewDev& vd = a.views[view];
-        if (kv == 0) a.draw_table[a.draw + view] = vd.draw;
+        const uint32_t kv = g - view * (uint32_t)a.n_tris;
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < (uint32_t)kMaxBatchMeshes; ++q)
+            if (q < a.n_meshes && kv >= a.mesh_off[q]) m = q;
+        const int k = (int)(kv - a.mesh_off[m]);
+        const uint32_t d = view * a.n_meshes + m;
+        const ViewDev& vd = a.views[d];
+        if (k == 0) a.draw_table[a.draw + d] = vd.draw;
         uint32_t c0 = 0, c1 = 0;
-        setup_triangle(a, kv, true, c0, c1, vd.pmv, vd.nmat, a.draw + view, a.tri_base + g, vd.z_split);
+        if (a.n_meshes > 1u) {  // (the triangle's own mesh: indices, positions, normals, texture vertices)
+            SetupArgs b = a;
+            b.idx = a.m_idx[m]; b.pos = a.m_pos[m]; b.nrm = a.m_nrm[m]; b.uvw = a.m_uvw[m];
+            setup_triangle(b, k, true, c0, c1, vd.pmv, vd.nmat, a.draw + d, a.tri_base + g, vd.z_split);
+        } else {
+            setup_triangle(a, k, true, c0, c1, vd.pmv, vd.nmat, a.draw + d, a.tri_base + g, vd.z_split);
+        }
         a.half_cnt[2 * (size_t)(a.tri_base + g)] = c0;  // (setup_triangle leaves the counts to its caller when `fused`)
         a.half_cnt[2 * (size_t)(a.tri_base + g) + 1] = c1;
         return;
@@ -1717,6 +1740,7 @@ struct ShadeArgs {
     // batched views (k_shade<false, false, true>): the grid is the views stacked in y; view v owns block rows
     // [v * view_blk_rows, (v + 1) * view_blk_rows), plane pixels from v * view_pix and draw-table entry v
     uint32_t view_blk_rows, view_pix;
+    uint32_t view_meshes;  // batched views: draws (meshes) per view; 1: draw-table entry v is view v's
     uint32_t blk_y0;  // first block row of the launch (band contexts, boxed launches; 0 otherwise)
     uint32_t blk_x0;  // first block column of the launch (boxed launches)
     uint32_t launch_rows;  // batched views: block rows per view in this launch
@@ -2129,8 +2153,18 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
         };
         // (a resolve for depth only, the snapshot of a shadow map: no shading, no colour plane)
         if (!(a.out_mask & 1u)) {
-        } else if (VIEWS) {
+        } else if (VIEWS && a.view_meshes <= 1u) {
             finish(uniform_drawdev(a.draws + view));  // (the batch's draws are its views, in order)
+        } else if (VIEWS) {
+            // several meshes per view: a wave's pixels belong to one view, i.e. to at most view_meshes draws -- one round per
+            // draw present in the wave, its constants through the scalar cache as above
+            unsigned long long todo = __ballot(true);
+            while (todo) {
+                const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)s.draw, __builtin_ctzll(todo));
+                const bool mine = s.draw == d;
+                if (mine) finish(uniform_drawdev(a.draws + d));
+                todo &= ~__ballot(mine);
+            }
         } else if (__all(s.draw == 0u)) finish(a.draw0);  // kernel argument: scalar registers
         else finish(a.draws[s.draw]);
       };

@@ -379,6 +379,23 @@ def render_views(model_renderer_state, mesh_component, shaders, out_mask=_ffi.TR
     _ffi.check(s._ctx, rc, "tr_render_views")
 
 
+def render_views_multi(model_renderer_state, mesh_components, shaders, out_mask=_ffi.TR_OUT_RGBA8):
+    """`render_views` for the reference's own scene: every iteration of its loop draws several meshes (main.rs:272-273:
+    the head, then the eye parented to it).  `shaders[v][m]` is the shader of mesh m under view v (its model_view holds
+    the mesh's local_to_world_matrix, parents folded in: mod.rs:67-84).  One batch, one slice per view
+    (tr_render_views_multi)."""
+    s = model_renderer_state
+    n_views, n_meshes = len(shaders), len(mesh_components)
+    arr = (_ffi.DrawParams * (n_views * n_meshes))()
+    for v, row in enumerate(shaders):
+        assert len(row) == n_meshes
+        for m, sh in enumerate(row):
+            arr[v * n_meshes + m] = make_draw_params(s, sh, mesh_components[m].texture, mesh_components[m].normal_map)
+    handles = (C.c_void_p * n_meshes)(*[s._mesh_handle(mc.mesh) for mc in mesh_components])
+    rc = s._lib.tr_render_views_multi(s._ctx, n_meshes, handles, arr, n_views, out_mask)
+    _ffi.check(s._ctx, rc, "tr_render_views_multi")
+
+
 def make_shade_ext(state, ext):
     x = _ffi.ShadeExt()
     x.model = ext.model
