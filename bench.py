@@ -450,6 +450,8 @@ def main():
 
     # ---- algorithmic bytes of the shade pass (SURVEY.md 8(d) / DESIGN.md):
     # W*H*(8 B winner-key read + 4 B RGBA8 write) + visible_tris*320 B + sum(min(texture bytes, shaded_px*16 B))
+    grid = (C.c_uint32 * 4)()
+    lib.tr_get_shade_launch(ctx, grid)  # (of the timed kind of frame: before the plane requests below resolve the whole frame)
     tri = st.triangle_ids(_ffi.TR_LAYOUT_ROW_MAJOR)
     shaded_px = int((tri != 0xFFFFFFFF).sum())
     vis_tris = int(np.unique(tri[tri != 0xFFFFFFFF]).size)
@@ -461,7 +463,7 @@ def main():
                 seen.add(id(img))
                 tex_bytes += min(img.shape[0] * img.shape[1] * 4, shaded_px * 16)
     shade_bytes = W * H * 12 + vis_tris * 320 + tex_bytes
-    traffic = None
+    traffic, pmc = None, {}
     try:  # HBM bytes per k_shade launch from the committed PMC passes (same workload only)
         import glob
 
@@ -472,6 +474,21 @@ def main():
         pass
     shade_s = stages_us["shade"] * 1e-6
     achieved = shade_bytes / shade_s / 1e9 if shade_s > 0 else 0.0
+    # the bytes of the blocks the boxed launch actually covers (it never reads or writes W*H*12 B), and the pass priced
+    # against what bounds it besides bytes: VALU issue, every instruction at the f64 rate of tools/valu_rates.hip
+    launched_px = int(grid[0]) * int(grid[1]) * max(1, int(grid[2])) * int(grid[3])
+    launched_bytes = min(launched_px, W * H) * 12 + vis_tris * 320 + tex_bytes
+    roofline_valu = None
+    try:
+        insts = pmc.get("k_shade_valu_insts_per_launch") if traffic is not None else None
+        if insts and shade_s > 0:
+            floor_us = insts * 5.0 / 1024.0 / 2400.0  # wave-instructions x 5 cycles / 1024 SIMDs / 2.4 GHz
+            roofline_valu = {"bound": "valu-issue", "kernel": pmc.get("k_shade_kernel"), "valu_wave_insts_per_launch": insts,
+                             "cycles_per_inst": 5.0, "simds": 1024, "clock_ghz": 2.4, "floor_us": floor_us,
+                             "frac": floor_us / stages_us["shade"],
+                             "note": "every VALU wave-instruction priced at the f64 multiply-add issue rate (5 cycles per wave64 at full occupancy, tools/valu_rates.hip): an upper estimate of the issue floor"}
+    except NameError:
+        pass
 
     out = {
         "metric": "frames/sec at 4K (african_head 3840x2160, clear+draw+resolve)",
@@ -485,9 +502,12 @@ def main():
         "mfragments_per_s": fps * frags / 1e6, "single_context_fps": single_fps, "latency_us": latency_us,
         "fragments_per_frame": frags, "samples_per_frame": counters["samples"], "shaded_px_per_frame": shaded_px,
         "stages_us": stages_us,
-        "roofline": {"bound": "hbm", "kernel": "k_shade", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_shade" if colour_exact_env else "k_shade_fused", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes": shade_bytes, "avg_launch_us": stages_us["shade"]},
+                     "algorithmic_bytes": shade_bytes, "avg_launch_us": stages_us["shade"],
+                     "launched_bytes": launched_bytes, "launched_workgroups": [int(grid[0]), int(grid[1]), int(grid[2])],
+                     "launched_gbs": launched_bytes / shade_s / 1e9 if shade_s > 0 else 0.0},
+        "roofline_valu": roofline_valu,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, draws)

@@ -126,6 +126,7 @@ extern "C" {
     pub fn tr_get_stream(ctx: *mut tr_context, out_hip_stream: *mut *mut c_void) -> c_int;
     pub fn tr_device_ptr_rgba8(ctx: *mut tr_context, out_dev_ptr: *mut *mut c_void) -> c_int;
     pub fn tr_profile_enable(ctx: *mut tr_context, enable: c_int) -> c_int;
+    pub fn tr_get_shade_launch(ctx: *mut tr_context, out: *mut u32) -> c_int;
     pub fn tr_profile_read(ctx: *mut tr_context, ms: *mut f64, counts: *mut u64, reset: c_int) -> c_int;
     // loading surface: helpers::load_model (helpers/mod.rs:352-355), load_rgba_img_from_file + flip_vertically (:93-96, 291-302)
     pub fn tr_obj_load(path: *const c_char, out: *mut *mut tr_obj) -> c_int;

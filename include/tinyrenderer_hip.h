@@ -274,6 +274,10 @@ int tr_device_ptr_rgba8(tr_context* ctx, void** out_dev_ptr); /* u32[W*H], row-m
  * [4] tile raster (tile mode) / winner pass (global mode) [5] shade;
  * counts[i] = number of launches accumulated. */
 int tr_profile_enable(tr_context* ctx, int enable);
+/* Shape of the last shade launch: out[0..2] = workgroups in x, y, z (z = views of a batch; all 0: nothing was
+ * launched), out[3] = pixels per workgroup.  The RGBA8-only resolve launches the blocks of the frame's screen box
+ * only: bench.py prices the bytes of the blocks actually launched with it (roofline.launched_bytes). */
+int tr_get_shade_launch(tr_context* ctx, uint32_t out[4]);
 int tr_profile_read(tr_context* ctx, double ms[6], uint64_t counts[6], int reset);
 
 /* ---- loading surface (host only; no context or GPU needed) ------------------------------

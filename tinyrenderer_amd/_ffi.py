@@ -47,7 +47,7 @@ EXPORTS = [
     "tr_obj_normals", "tr_obj_indices", "tr_obj_free", "tr_image_load_rgba8", "tr_image_size", "tr_image_data",
     "tr_image_free", "tr_load_error", "tr_image_write_png", "tr_selftest_arithmetic",
     "tr_draw_ext", "tr_shadow_map_create", "tr_shadow_map_update", "tr_shadow_map_destroy", "tr_host_alloc", "tr_host_free",
-    "tr_read_rgba8_static", "tr_create_views", "tr_render_views", "tr_select_view", "tr_set_colour_exact", "tr_render_views_multi",
+    "tr_read_rgba8_static", "tr_create_views", "tr_render_views", "tr_select_view", "tr_set_colour_exact", "tr_render_views_multi", "tr_get_shade_launch",
 ]
 
 
@@ -124,6 +124,7 @@ def load():
         "tr_get_stream": (i32, [vp, C.POINTER(vp)]),
         "tr_device_ptr_rgba8": (i32, [vp, C.POINTER(vp)]),
         "tr_profile_enable": (i32, [vp, i32]),
+        "tr_get_shade_launch": (i32, [vp, C.POINTER(u32)]),
         "tr_profile_read": (i32, [vp, pd, C.POINTER(C.c_uint64), i32]),
         "tr_version": (C.c_char_p, []),
         "tr_set_band": (i32, [vp, i32, i32]),

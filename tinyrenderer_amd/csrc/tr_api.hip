@@ -70,6 +70,7 @@ struct tr_context {
     int y_lo = 0, y_hi = 0;
     int shaded_lo = 0, shaded_hi = 0;  // rows the last shade launch covered (a band context shades its band's rows only)
     PixBox frame_box;   // where this frame's draws can land a sample (projected mesh boxes, a margin added); tr_clear empties it
+    uint32_t last_shade_grid[3] = {0, 0, 0};  // workgroups of the last shade launch (tr_get_shade_launch)
     PixBox paint_box;   // where the colour plane may differ from the background after the last shade launch
     bool depth_split = true;  // TR_DEPTH_SPLIT: draws that use k_small / k_mid split their triangles at the depth of the mesh box's centre
     bool split_any = false;   // a draw of this frame did
@@ -1790,6 +1791,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         c->shaded_lo = c->y_lo;
         c->shaded_hi = c->y_hi;
         sa.trace = nullptr;
+        c->last_shade_grid[0] = nothing ? 0u : sgrid.x; c->last_shade_grid[1] = nothing ? 0u : sgrid.y; c->last_shade_grid[2] = nothing ? 0u : sgrid.z;
         static const char* shade_trace = env_diag("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
         (void)shade_trace;
         // the fused colour arithmetic (+-1 LSB) unless the caller asked for the reference's operations or for the f64 colour plane
@@ -2020,6 +2022,13 @@ int tr_set_band(tr_context* c, int y_lo, int y_hi) {
     if (c->max_views > 1 && (y_lo != 0 || y_hi != c->H)) return fail(c, TR_ERR_UNSUPPORTED, "no bands on a tr_create_views context");
     c->y_lo = y_lo;
     c->y_hi = y_hi;
+    return TR_OK;
+}
+
+int tr_get_shade_launch(tr_context* c, uint32_t out[4]) {
+    if (!c || !out) return TR_ERR_INVALID;
+    out[0] = c->last_shade_grid[0]; out[1] = c->last_shade_grid[1]; out[2] = c->last_shade_grid[2];
+    out[3] = (uint32_t)(kShadeBW * kShadeBH);
     return TR_OK;
 }
 
