@@ -1943,6 +1943,8 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
         int tile = (y >> a.th_shift) * a.tiles_x + (x >> a.tw_shift);
         listed = a.tile_off[tile + 1] > a.tile_off[tile];
     }
+    // (requesting the key before the block flags are back, so that a covered wave saves a round trip, makes the idle waves
+    // of the boxed launch wait for a load they do not need: 34.3 against 32.4 us)
     unsigned long long key = listed ? a.wkey[ppix] : kKeyNone;
     if (a.self_clean && key != kKeyNone) {  // leave the planes cleared for the next frame
         a.wkey[ppix] = kKeyNone;
