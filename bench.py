@@ -58,7 +58,12 @@ def cpu_baseline(W, H, draws, budget_s=12.0):
             assert rc == 0
         times.append(time.perf_counter() - t0)
     med = float(np.median(times[1:]))
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port",
+    cpu_model = ""
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model, "host_cpus": os.cpu_count(),
             "sample": f"{len(times) - 1} frames of the same {W}x{H} african_head frame (median), "
                       "C++ restatement of the reference (oracle/), single thread, clear + draw, no present",
             "ms_per_frame": med * 1e3, "fragments_per_frame": st.counters()["fragments"]}
