@@ -91,6 +91,33 @@ def test_cpp_frame_loop_renders_the_reference_frame(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_frame_loop_in_batches_of_iterations(oracle, tmp_path):
+    """The same loop rendered ahead in batches of 4 iterations of BOTH meshes (render_views_multi ->
+    tr_render_views_multi): 7 iterations = a batch of 4 and one of 3; the last slice is the frame for time = 7."""
+    import scene_util as SU
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd import scenes
+
+    exe = os.path.join(ROOT, "examples", "frame_loop")
+    W, Hh = 853, 480
+    out = str(tmp_path / "frame7.rgba")
+    res = subprocess.run([exe, H.ASSET_DIR, "7", str(W), str(Hh), out, "1", "4"], capture_output=True, text=True, timeout=110)
+    assert res.returncode == 0, res.stderr
+    assert "batches of 4 iterations" in res.stdout
+    got = np.fromfile(out, dtype=np.uint8).reshape(Hh, W, 4)
+    head, eye = SU.component("head"), SU.component("eye_inner")
+    head.transform.set_rotation((0.025 * 7, 0.0, 0.0))
+    eye.parent = head
+    try:
+        draws = [(head, scenes.shader_for(head, W, Hh)), (eye, scenes.shader_for(eye, W, Hh))]
+        want = SU.oracle_render(oracle, W, Hh, draws)["present"]
+    finally:
+        eye.parent = None
+        head.transform.set_rotation((0.025, 0.0, 0.0))
+    SU.assert_image(got, want, "frame_loop batches")
+
+
+@pytest.mark.gpu
 def test_cpp_orbit_views_batch_renders_the_oracle_view(oracle, tmp_path):
     """examples/orbit_views: render_views (tr_render_views) from the C++ layer; view 5 of a 12-view orbit of
     diablo3_pose, taken out of the second batch of 4, equals the oracle's frame for that camera."""
