@@ -194,6 +194,10 @@ struct tr_context {
     std::string err;
     // profiling
     bool precheck = true;          // plain-load filter in front of the depth atomics
+#ifndef TR_BOX_DEFAULT
+#define TR_BOX_DEFAULT 1
+#endif
+    bool raster_box = TR_BOX_DEFAULT != 0;  // k_raster depth pass: chunks reduce their samples per pixel in LDS first
     bool precheck_winner = false;  // ... and in front of the winner atomics
     bool skip_dead = true;         // winner pass skips chunks the depth pass found dead
     bool fused_front = true;       // small draws: transform + setup + scan in one launch (TR_FUSED_FRONT)
@@ -415,6 +419,7 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.clean_nan = nullptr;
     ra.need_shade = c->deferred.empty() ? nullptr : c->need_shade;
     ra.mid_shift = mid_shift_for(h_hi - h_lo);
+    ra.box = c->raster_box ? 1u : 0u;
     ra.view_tris = c->view_tris;
     ra.view_pix = (uint32_t)((size_t)c->W * c->H);
     ra.view_blk = c->blk_per_view;
@@ -541,6 +546,16 @@ void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block
     }
 #endif
     (void)dbg;
+    if (PASS == 0 && precheck) {
+        if (threads == 128) hipLaunchKernelGGL((k_raster_depth<128, TR_DEPTH_OCC_128>), grid, block, 0, stream, ra);
+        else hipLaunchKernelGGL((k_raster_depth<256, TR_DEPTH_OCC_256>), grid, block, 0, stream, ra);
+        return;
+    }
+    if (PASS == 1 && !precheck) {
+        if (threads == 128) hipLaunchKernelGGL((k_raster_winner<128, TR_WINNER_OCC_128>), grid, block, 0, stream, ra);
+        else hipLaunchKernelGGL((k_raster_winner<256, TR_WINNER_OCC_256>), grid, block, 0, stream, ra);
+        return;
+    }
     if (threads == 128) { if (precheck) TR_LAUNCH(true, false, 128); else TR_LAUNCH(false, false, 128); }
     else { if (precheck) TR_LAUNCH(true, false, 256); else TR_LAUNCH(false, false, 256); }
 #undef TR_LAUNCH
@@ -813,6 +828,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (const char* e = env_diag("TR_RASTER_PRECHECK")) c->precheck = std::atoi(e) != 0;
     if (const char* e = env_diag("TR_RASTER_PRECHECK_WINNER")) c->precheck_winner = std::atoi(e) != 0;
     if (const char* e = env_diag("TR_RASTER_SKIP_DEAD")) c->skip_dead = std::atoi(e) != 0;
+    if (const char* e = env_diag("TR_RASTER_BOX")) c->raster_box = std::atoi(e) != 0;
     if (const char* e = env_opt("TR_FUSED_FRONT")) c->fused_front = std::atoi(e) != 0;
     if (const char* e = env_opt("TR_RASTER_THREADS")) {
         const int t = std::atoi(e);

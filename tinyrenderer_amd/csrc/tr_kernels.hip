@@ -928,6 +928,7 @@ struct RasterArgs {
     uint32_t tiled;             // the planes' layout this frame: 0 row-major, 1 tiles of 4 x 2 pixels (plane_index)
     uint32_t phase;             // k_small / k_mid depth pass: 0 every triangle, 1 the near ones only, 2 the far ones (kFlagFar) only
     uint32_t mid_shift;         // k_mid: log2 of the halves a wave looks up at once (0 .. 6)
+    uint32_t box;               // k_raster depth pass: 1 = a chunk's samples are reduced in an LDS box of pixels first
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
     unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
                                 // ticks, samples | block << 32)
@@ -1048,6 +1049,20 @@ __global__ __launch_bounds__(256) void k_scanlines(RasterArgs a) {
 // waves waiting for its records, the better throughput when frames are in flight on several streams
 // (measured at 4K: one context 6 840 / 6 430 frames/s, four contexts 9 750 / 10 450).
 constexpr int kChunkSlots = 64;
+#ifndef TR_BOX_PIX
+#define TR_BOX_PIX 1024
+#endif
+#ifndef TR_BOX_SUB
+#define TR_BOX_SUB 4
+#endif
+#ifndef TR_BOX_PIX_128
+#define TR_BOX_PIX_128 512
+#endif
+constexpr int kBoxPixMax = TR_BOX_PIX;     // pixels a chunk can hold in its LDS boxes (8 bytes each): workgroups of 256 threads
+constexpr int kBoxPix128 = TR_BOX_PIX_128; // ... of 128 threads (frames in flight: the LDS then bounds the waves per SIMD)
+constexpr int kBoxSubShift = TR_BOX_SUB;   // 2^this consecutive slots of a chunk share one box
+constexpr int kBoxSubs = kChunkSlots >> kBoxSubShift;
+static_assert(kBoxPixMax <= 2048 && kBoxPix128 <= 2048, "the flush's division by a box's width is exact below 2048 entries only");
 
 
 // One workgroup per chunk of 64 consecutive slots (chunks are aligned to the frame's slot
@@ -1057,8 +1072,8 @@ constexpr int kChunkSlots = 64;
 // depth / winner atomics of one wave-instruction fall into contiguous 8-byte slots.
 // VIEWS: the frame is a batch of views of one mesh (tr_render_views); a slot's samples land in the plane slice
 // and the shade blocks of its triangle's view.
-template <int PASS, bool PRECHECK, bool DBG, int kRasterThreads, bool VIEWS = false>
-__global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
+template <int PASS, bool PRECHECK, bool DBG, int kRasterThreads, bool VIEWS>
+__device__ __forceinline__ void raster_body(const RasterArgs& a) {
     // (timing experiments and the per-chunk timeline live in the DBG instantiations only)
     const int dbg_mode = DBG ? a.debug : 0;
     unsigned long long* const dbg_trace = DBG ? a.trace : nullptr;
@@ -1069,11 +1084,28 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
     __shared__ uint32_t sView[VIEWS ? kChunkSlots : 1];  // view of each slot's triangle
     const double* sRecD = reinterpret_cast<const double*>(sRec4);
     const unsigned long long* sRecU = reinterpret_cast<const unsigned long long*>(sRec4);
+    // depth pass, box form: the minima of the chunk's samples per pixel of the chunk's screen box (empty = all ones)
+    constexpr bool kBoxOn = PASS == 0 && PRECHECK && !VIEWS;
+    constexpr int kBoxPix = kRasterThreads == 128 ? kBoxPix128 : kBoxPixMax;
+    __shared__ unsigned long long sBox[kBoxOn ? kBoxPix : 1];
+    __shared__ uint4 sBoxA[kBoxOn ? kBoxSubs : 1];        // per box: x0, y0, width | height << 16 (0: not boxed), first entry
+    __shared__ uint32_t sBoxMagic[kBoxOn ? kBoxSubs : 1];  // per box: 2^21 / width + 1
+    __shared__ uint32_t sBoxEnd[kBoxOn ? kBoxSubs : 1];    // per box: one past its last entry
+    __shared__ uint32_t sBoxHdr[2];                        // entries in use, 1 = some samples of the chunk are not boxed
+    const bool box_on = kBoxOn && a.box != 0;
+    if (box_on)
+        for (uint32_t p = threadIdx.x; p < (uint32_t)kBoxPix; p += (uint32_t)kRasterThreads) sBox[p] = ~0ull;
 
     // samples a thread keeps in flight: measured on MI355X at 4K, the depth pass (bound by the
     // atomic rate) is fastest with 1 (58 us; 63 with 2, 68 with 4), the winner pass with 3 (72 VGPRs: 30.1 us;
     // 2: 30.7, 4 at 82 VGPRs: 31.2)
-    constexpr int kBatch = PASS == 0 ? 1 : 3;
+#ifndef TR_WINNER_BATCH
+#define TR_WINNER_BATCH 3
+#endif
+#ifndef TR_DEPTH_BATCH
+#define TR_DEPTH_BATCH 2
+#endif
+    constexpr int kBatch = PASS == 0 ? TR_DEPTH_BATCH : TR_WINNER_BATCH;
     const int lane = threadIdx.x & 63;
     const uint32_t band_rows = (uint32_t)(a.y_hi - a.y_lo);
     const bool wave0 = threadIdx.x < 64;
@@ -1201,8 +1233,64 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
             if (lane == 0) sPre[0] = 0;
             if (VIEWS) sView[lane] = (uint32_t)(sRecU[lane * 8 + 7] >> kKeyTriShift) / a.view_tris;  // (an empty slot: view 0, never read)
         }
+        if (box_on && (threadIdx.x >> 6) == kRasterThreads / 64 - 1) {
+            // the screen box of every group of 2^kBoxSubShift slots from its records' end points: a scanline's pixel
+            // coordinates are monotone in j (every operation of x(j) = ax + (j * inv) * dx is), so samples 0 and hres
+            // bound them.  Boxes get their entries in slot order while they fit; the samples of the others go to the plane
+            // one by one.
+            const double* r = sRecD + lane * 8;
+            const uint32_t hres = (uint32_t)(sRecU[lane * 8 + 7] & kRecHresMask);
+            int x_lo = 0x7fffffff, x_hi = -1, y_lo = 0x7fffffff, y_hi = -1;
+            if (hres) {
+                const double sp = (double)hres * r[6];
+                const int xa = pixel_coord_raw(r[0]), xb = pixel_coord_raw(r[0] + sp * r[3]);
+                const int ya = pixel_coord_raw(r[1]), yb = pixel_coord_raw(r[1] + sp * r[4]);
+                const int xl = max(min(xa, xb), 0), xh = min(max(xa, xb), a.W - 1);
+                const int yl = max(min(ya, yb), a.y_lo), yh = min(max(ya, yb), a.y_hi - 1);
+                if (xl <= xh && yl <= yh) { x_lo = xl; x_hi = xh; y_lo = yl; y_hi = yh; }
+            }
+#pragma unroll
+            for (int d = 1; d < (1 << kBoxSubShift); d <<= 1) {
+                x_lo = min(x_lo, __shfl_xor(x_lo, d, 64));
+                y_lo = min(y_lo, __shfl_xor(y_lo, d, 64));
+                x_hi = max(x_hi, __shfl_xor(x_hi, d, 64));
+                y_hi = max(y_hi, __shfl_xor(y_hi, d, 64));
+            }
+            const bool leader = (lane & ((1 << kBoxSubShift) - 1)) == 0;
+            const uint32_t w = x_hi >= x_lo ? (uint32_t)(x_hi - x_lo + 1) : 0u;
+            const uint32_t h = y_hi >= y_lo ? (uint32_t)(y_hi - y_lo + 1) : 0u;
+            const bool has = w != 0u && h != 0u;
+            const bool fits = has && w <= 1024u && (unsigned long long)w * h <= (unsigned long long)kBoxPix;
+            const uint32_t n = leader && fits ? w * h : 0u;
+            uint32_t incl = n;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            const bool boxed = fits && incl <= (uint32_t)kBoxPix;
+            const unsigned long long m_boxed = __ballot(leader && boxed);
+            const unsigned long long m_open = __ballot(leader && has && !boxed);
+            const uint32_t used = m_boxed ? (uint32_t)__shfl((int)incl, 63 - __builtin_clzll(m_boxed), 64) : 0u;
+            if (leader) {
+                const int b = lane >> kBoxSubShift;
+                sBoxA[b] = make_uint4((uint32_t)x_lo, (uint32_t)y_lo, boxed ? (w | (h << 16)) : 0u, incl - n);
+                sBoxMagic[b] = boxed ? (1u << 21) / w + 1u : 0u;
+                sBoxEnd[b] = boxed ? incl : (incl < used ? incl : used);
+            }
+            if (lane == 0) {
+                sBoxHdr[0] = used;
+                sBoxHdr[1] = m_open ? 1u : 0u;
+            }
+        }
         __syncthreads();
         const uint32_t total = sPre[64];
+        uint32_t box_n = 0;   // entries of sBox this chunk uses (uniform)
+        bool box_open = true;  // some samples go to the plane directly (uniform)
+        if (box_on) {
+            box_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)sBoxHdr[0]);
+            box_open = __builtin_amdgcn_readfirstlane((int)sBoxHdr[1]) != 0 || box_n == 0u;
+        }
         if (dbg_trace && threadIdx.x == 0) tr_t1 = wall_clock64();
         // first samples of slots 8, 16, .., 56: the same for every lane (scalar registers); a sample
         // finds its group of 8 slots among them without touching LDS
@@ -1270,12 +1358,24 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                             st[u] = 1;
                             enc[u] = encode_depth(dist);
                             if (PASS == 0 && dist == -__builtin_huge_val()) atomicOr(a.flags, 1u << 3);
+                            if (kBoxOn && box_n) {
+                                const uint4 bh = sBoxA[sidx >> kBoxSubShift];
+                                const uint32_t bw = bh.z & 0xffffu, bx = (uint32_t)ix - bh.x, by = (uint32_t)iy - bh.y;
+                                if (bx < bw && by < (bh.z >> 16)) {  // (else: not boxed, or a scanline that is not monotone)
+                                    atomicMin(&sBox[bh.w + by * bw + bx], enc[u]);
+                                    st[u] = 0;  // settled by the flush below
+                                } else if (!box_open) {  // (every box of the chunk fitted, so nobody loads the plane: never seen)
+                                    atomicMin(&a.depth[pix[u]], enc[u]);
+                                    any_live = true;
+                                    st[u] = 0;
+                                }
+                            }
                         }
                     }
                 }
             }
             unsigned long long cur[kBatch];
-            const bool want_load = (PASS == 1 || PRECHECK) && dbg_mode != 2;
+            const bool want_load = (PASS == 1 || PRECHECK) && dbg_mode != 2 && !(kBoxOn && !box_open);
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)  // (lanes with nothing to do read pixel 0: no branch around the load)
                 cur[u] = want_load ? a.depth[st[u] == 1 ? pix[u] : 0u] : 0ull;
@@ -1343,6 +1443,43 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
                 }
             }
         }
+        if (kBoxOn && box_n) {
+            // ---- flush: the boxes' minima go to the plane, one load + at most one atomic per touched PIXEL; consecutive
+            // lanes = consecutive pixels of a box row.  Entries are left empty for the next chunk.
+            __syncthreads();
+            uint32_t ends[kBoxSubs > 1 ? kBoxSubs - 1 : 1] = {0u};
+#pragma unroll
+            for (int b = 0; b < kBoxSubs - 1; ++b) ends[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sBoxEnd[b]);
+            constexpr int kFlush = 4;
+            for (uint32_t p0 = threadIdx.x; p0 < box_n; p0 += (uint32_t)(kRasterThreads * kFlush)) {
+                unsigned long long v[kFlush], cur[kFlush];
+                uint32_t px[kFlush];
+#pragma unroll
+                for (int u = 0; u < kFlush; ++u) {
+                    const uint32_t p = p0 + (uint32_t)(u * kRasterThreads);
+                    v[u] = p < box_n ? sBox[p] : ~0ull;
+                    px[u] = 0;
+                    if (v[u] != ~0ull) {
+                        sBox[p] = ~0ull;
+                        uint32_t b = 0;
+#pragma unroll
+                        for (int i = 0; i < kBoxSubs - 1; ++i) b += p >= ends[i] ? 1u : 0u;
+                        const uint4 bh = sBoxA[b];
+                        const uint32_t bw = bh.z & 0xffffu, pl = p - bh.w;
+                        const uint32_t by = (pl * sBoxMagic[b]) >> 21, bx = pl - by * bw;  // pl / bw, exact for pl < 2048 and bw <= 1024
+                        px[u] = plane_index(bh.x + bx, bh.y + by, (uint32_t)a.W, a.tiled != 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kFlush; ++u) cur[u] = v[u] != ~0ull && dbg_mode != 2 ? a.depth[px[u]] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < kFlush; ++u) {
+                    if (v[u] == ~0ull) continue;
+                    any_live |= v[u] <= cur[u];
+                    if (v[u] < cur[u] && dbg_mode == 0) atomicMin(&a.depth[px[u]], v[u]);
+                }
+            }
+        }
         // (also the barrier before the next chunk rewrites LDS)
         const int live = __syncthreads_or(any_live ? 1 : 0);
         if (dbg_trace && threadIdx.x == 0 && chunk - c_lo < a.trace_cap) {
@@ -1364,6 +1501,33 @@ __global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
         // them; lane 0 takes part in every one its wave casts); cnt_scan is per lane
         flush_counts();
     }
+}
+
+template <int PASS, bool PRECHECK, bool DBG, int kRasterThreads, bool VIEWS = false>
+__global__ __launch_bounds__(kRasterThreads) void k_raster(RasterArgs a) {
+    raster_body<PASS, PRECHECK, DBG, kRasterThreads, VIEWS>(a);
+}
+// The two passes in the form frames are rendered with (one view; filter in front of the depth atomics, none in front of the
+// winner's), each held to the registers of kOcc waves per SIMD.
+#ifndef TR_DEPTH_OCC_128
+#define TR_DEPTH_OCC_128 8
+#endif
+#ifndef TR_DEPTH_OCC_256
+#define TR_DEPTH_OCC_256 8
+#endif
+#ifndef TR_WINNER_OCC_128
+#define TR_WINNER_OCC_128 8
+#endif
+#ifndef TR_WINNER_OCC_256
+#define TR_WINNER_OCC_256 8
+#endif
+template <int kRasterThreads, int kOcc>
+__global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(kOcc, kOcc))) void k_raster_depth(RasterArgs a) {
+    raster_body<0, true, false, kRasterThreads, false>(a);
+}
+template <int kRasterThreads, int kOcc>
+__global__ __launch_bounds__(kRasterThreads) __attribute__((amdgpu_waves_per_eu(kOcc, kOcc))) void k_raster_winner(RasterArgs a) {
+    raster_body<1, false, false, kRasterThreads, false>(a);
 }
 
 // ---------------------------------------------------------------- small triangles
@@ -1690,6 +1854,10 @@ template __global__ void k_raster<0, true, false, 128, true>(RasterArgs);
 template __global__ void k_raster<1, false, false, 128, true>(RasterArgs);
 template __global__ void k_raster<0, true, false, 256, true>(RasterArgs);
 template __global__ void k_raster<1, false, false, 256, true>(RasterArgs);
+template __global__ void k_raster_depth<128, TR_DEPTH_OCC_128>(RasterArgs);
+template __global__ void k_raster_depth<256, TR_DEPTH_OCC_256>(RasterArgs);
+template __global__ void k_raster_winner<128, TR_WINNER_OCC_128>(RasterArgs);
+template __global__ void k_raster_winner<256, TR_WINNER_OCC_256>(RasterArgs);
 template __global__ void k_raster<0, true, false, 128>(RasterArgs);
 template __global__ void k_raster<1, true, false, 128>(RasterArgs);
 template __global__ void k_raster<0, false, false, 128>(RasterArgs);
