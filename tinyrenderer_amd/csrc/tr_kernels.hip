@@ -2369,8 +2369,11 @@ __global__ __launch_bounds__(kShadeBW * kShadeBH) void k_shade(ShadeArgs a) {
 }
 // ... and the fused one, held to 64 VGPRs so that 8 waves fit a SIMD (no spills; 80 VGPRs and 6 waves otherwise:
 // 32.0 against 33.9 us at 4K)
+#ifndef TR_SHADE_VIEWS_OCC
+#define TR_SHADE_VIEWS_OCC 7  // (the views form spills 44 bytes a lane at 64 VGPRs: 34.3 -> 35.3 k views/s for the 1080p orbit at 72)
+#endif
 template <bool VIEWS>
-__global__ __launch_bounds__(kShadeBW * kShadeBH) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_shade_fused(ShadeArgs a) {
+__global__ __launch_bounds__(kShadeBW * kShadeBH) __attribute__((amdgpu_waves_per_eu(VIEWS ? TR_SHADE_VIEWS_OCC : 8, VIEWS ? TR_SHADE_VIEWS_OCC : 8))) void k_shade_fused(ShadeArgs a) {
     shade_body<false, false, VIEWS, true, true>(a);
 }
 template __global__ void k_shade<false, false>(ShadeArgs);
