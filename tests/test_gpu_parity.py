@@ -878,6 +878,76 @@ def test_fused_setup_prefix_poll_gives_up_instead_of_hanging(oracle):
     SU.assert_parity(o, g)
 
 
+_BOX_CHILD = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import scene_util as SU
+from tinyrenderer_amd import _ffi, scenes, helpers as H_
+from tinyrenderer_amd.model_renderer import ModelRendererState, BuiltinShader, clear_screen, render_mesh_component
+import test_gpu_parity as T
+assert b"diag" in _ffi.load().tr_version()
+out = []
+def frame(W, Hh, draws, band=None, threads=None):
+    st = ModelRendererState(W, Hh)
+    try:
+        clear_screen(st)
+        if band is not None:
+            st.set_band(*band)
+        for mc, sh in draws:
+            render_mesh_component(st, mc, sh)
+        st.resolve(_ffi.TR_OUT_RGBA8 | _ffi.TR_OUT_Z | _ffi.TR_OUT_TRI_ID)
+        h = hashlib.sha256()
+        for a in (st.z_buffer, st.winner_keys(), st.present()):
+            h.update(np.ascontiguousarray(a).tobytes())
+        c = st.counters()
+        assert st.status_flags() == 0, hex(st.status_flags())
+        return h.hexdigest() + " %d %d" % (c["samples"], c["fragments"])
+    finally:
+        st.close()
+# the head (chunks whose boxes fit), a band of it, and triangles from slivers to most of a 2048-pixel row (boxes that do
+# not fit, scanlines wider than a box may be)
+W, Hh = 640, 360
+head = T._head_scene(W, Hh, with_eye=True)
+out.append(frame(W, Hh, head))
+out.append(frame(W, Hh, head, band=(96, 224)))
+rng = np.random.default_rng(11)
+v = np.zeros((60, 3)); v[:, 0] = rng.uniform(-0.98, 0.98, 60); v[:, 1] = rng.uniform(-0.98, 0.98, 60); v[:, 2] = rng.uniform(-0.9, 0.9, 60)
+vt = rng.uniform(0.02, 0.98, (60, 3)); vn = rng.normal(size=(60, 3))
+tris = [[a, a, a, b, b, b, c, c, c] for a, b, c in (rng.choice(60, 3, replace=False) for _ in range(24))]
+order = np.argsort(v[:, 0])
+tris += [[order[k]] * 3 + [order[k + 1]] * 3 + [order[k + 2]] * 3 for k in range(58)]
+obj = H_.Object(v.reshape(-1), vt.reshape(-1), vn.reshape(-1), np.array(tris, dtype=np.uint32).reshape(-1))
+mixed = [(T._synthetic_component(obj, seed=5), BuiltinShader(np.eye(4), np.eye(4), (0.3, 0.2, 1.0)))]
+out.append(frame(2048, 256, mixed))
+print("BOX-FRAMES " + " | ".join(out))
+"""
+
+
+def test_depth_pass_lds_boxes_against_the_per_sample_form(oracle):
+    """The depth pass reduces a chunk's samples per pixel in LDS boxes before it touches the plane.  The
+    diagnostic build can switch the boxes off (TR_RASTER_BOX=0: every sample loads the plane and issues its own atomic, the
+    form of rounds 1 and 2): both forms, with workgroups of 128 and of 256 threads (boxes of 512 and 1 024 pixels), must
+    leave the same depth plane, winner keys, image and counters -- for a scene whose boxes fit, for a band of it, and for
+    one with boxes that do not fit and scanlines wider than a box may be.  (Every other test checks the boxed form, the
+    release build's only one, against the oracle.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for box in ("0", "1"):
+        for threads in ("128", "256"):
+            env = dict(os.environ, TR_RASTER_BOX=box, TR_RASTER_THREADS=threads, TINYRENDERER_HIP_DIAG="1")
+            env.pop("TINYRENDERER_HIP_LIB", None)
+            res = subprocess.run([sys.executable, "-c", _BOX_CHILD, root], env=env, capture_output=True, text=True, timeout=200)
+            lines = [l for l in res.stdout.splitlines() if l.startswith("BOX-FRAMES ")]
+            assert res.returncode == 0 and lines, res.stdout + res.stderr
+            seen[(box, threads)] = lines[-1]
+    assert len(set(seen.values())) == 1, seen
+
+
 def test_boxed_shade_launch_follows_what_moves(oracle):
     """The cheap resolve launches only the blocks of the frame's screen box plus the box the previous launch painted:
     one context, frames whose content moves, shrinks, vanishes and comes back must each equal the oracle's image
