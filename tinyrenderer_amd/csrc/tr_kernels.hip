@@ -1049,6 +1049,9 @@ __global__ __launch_bounds__(256) void k_scanlines(RasterArgs a) {
 // waves waiting for its records, the better throughput when frames are in flight on several streams
 // (measured at 4K: one context 6 840 / 6 430 frames/s, four contexts 9 750 / 10 450).
 constexpr int kChunkSlots = 64;
+// The depth pass's LDS boxes; the values are the best of a sweep on one MI355X box (`make variant EXTRA=-D...`,
+// tools/ab_bench.sh): 2 048 pixels for 256 threads cost more in waves per SIMD than they save in atomics, 8-slot boxes send
+// 5 % fewer atomic requests than 16-slot ones and are no faster.
 #ifndef TR_BOX_PIX
 #define TR_BOX_PIX 1024
 #endif
@@ -1096,9 +1099,9 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
     if (box_on)
         for (uint32_t p = threadIdx.x; p < (uint32_t)kBoxPix; p += (uint32_t)kRasterThreads) sBox[p] = ~0ull;
 
-    // samples a thread keeps in flight: measured on MI355X at 4K, the depth pass (bound by the
-    // atomic rate) is fastest with 1 (58 us; 63 with 2, 68 with 4), the winner pass with 3 (72 VGPRs: 30.1 us;
-    // 2: 30.7, 4 at 82 VGPRs: 31.2)
+    // samples a thread keeps in flight, measured on MI355X at 4K: the winner pass is fastest with 3 (30.1 us; 2: 30.7,
+    // 4: 31.2); the depth pass was fastest with 1 while every sample loaded the plane and issued its own atomic (58 us;
+    // 63 with 2), and is with 2 now that its samples go to the LDS boxes (one context 8 230 against 8 090 frames/s)
 #ifndef TR_WINNER_BATCH
 #define TR_WINNER_BATCH 3
 #endif
