@@ -495,6 +495,26 @@ def main():
     except NameError:
         pass
 
+    # the raster pair beside it: the depth pass is the longest kernel of the frame and neither HBM- nor MFMA-bound -- its live
+    # stage times against the two floors its counters give (VALU issue at 4 cycles per wave-instruction; memory-side atomic
+    # service at the ~20 G requests/s of MI355X_MICROARCH.md), counters from the committed single-context PMC passes
+    raster_passes = None
+    if traffic is not None and "k_depth_valu_insts_per_launch" in pmc:
+        raster_passes = {"note": "live hipEvent times of this run (the 128-thread form when four contexts are alive); counters per launch from "
+                                 "profiles/ (rocprofv3 --pmc, one context, the 256-thread form); floors: VALU wave-instructions x 4 cycles / 1024 SIMDs / "
+                                 "2.4 GHz, atomic requests / 20 G/s"}
+        for short, stage in (("k_depth", "depth_pass"), ("k_winner", "winner_pass")):
+            insts, reqs = pmc.get(short + "_valu_insts_per_launch"), pmc.get(short + "_atomic_requests_per_launch")
+            e = {"kernel": pmc.get(short + "_kernel"), "avg_launch_us": stages_us[stage], "valu_wave_insts_per_launch": insts,
+                 "atomic_requests_per_launch": reqs, "hbm_bytes_per_launch": pmc.get(short + "_hbm_bytes_per_launch")}
+            if insts:
+                e["valu_floor_us"] = insts * 4.0 / 1024.0 / 2400.0
+            if reqs:
+                e["atomic_floor_us"] = reqs / 20e3
+            if stages_us[stage] > 0:
+                e["frac_of_larger_floor"] = max(e.get("valu_floor_us", 0.0), e.get("atomic_floor_us", 0.0)) / stages_us[stage]
+            raster_passes[stage] = e
+
     out = {
         "metric": "frames/sec at 4K (african_head 3840x2160, clear+draw+resolve)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -513,6 +533,7 @@ def main():
                      "launched_bytes": launched_bytes, "launched_workgroups": [int(grid[0]), int(grid[1]), int(grid[2])],
                      "launched_gbs": launched_bytes / shade_s / 1e9 if shade_s > 0 else 0.0},
         "roofline_valu": roofline_valu,
+        "raster_passes": raster_passes,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, draws)

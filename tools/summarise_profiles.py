@@ -71,6 +71,15 @@ if "hbm_bytes_per_launch" in sh:
     pmc["k_shade_hbm_bytes_per_launch"] = sh["hbm_bytes_per_launch"]
 if "SQ_INSTS_VALU" in sh:
     pmc["k_shade_valu_insts_per_launch"] = sh["SQ_INSTS_VALU"]
+# the raster pair (the larger part of the frame): what bench.py's `raster_passes` record quotes beside its live stage times
+for short, needle in (("k_depth", "k_raster_depth<256"), ("k_winner", "k_raster_winner<256")):
+    for k, e in pmc["kernels"].items():
+        if needle in k:
+            pmc[short + "_kernel"] = k
+            for c, name in (("SQ_INSTS_VALU", "valu_insts_per_launch"), ("TCC_EA0_ATOMIC_sum", "atomic_requests_per_launch"),
+                            ("hbm_bytes_per_launch", "hbm_bytes_per_launch")):
+                if c in e:
+                    pmc[f"{short}_{name}"] = e[c]
 json.dump(pmc, open(f"profiles/{tag}_hbm_pmc_4k.json", "w"), indent=1)
 # the same counters with four contexts in flight (working set 4 x 166 MB > the 256 MB Infinity Cache)
 pmc4 = {"source": "tools/collect_profiles.sh: rocprofv3 --pmc, one counter set per run, python3 bench.py (FOUR contexts in flight) "
