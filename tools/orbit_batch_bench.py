@@ -21,7 +21,7 @@ def main():
     from tinyrenderer_amd.model_renderer import ModelRendererState, make_draw_params
 
     lib = _ffi.load()
-    mc = SU.component("diablo")
+    mc = SU.component(os.environ.get("ORBIT_MESH", "diablo"))
     mc.transform.set_rotation((0.0, 0.0, 0.0))
     states = [ModelRendererState(W, H, max_views=batch) for _ in range(n_ctx)]
     shaders = [scenes.shader_for(mc, W, H, eye=scenes.orbit_eye(k, n)) for k in range(n)]
