@@ -98,14 +98,21 @@ def test_static_read_from_two_contexts_at_once_is_refused_not_raced():
 
     def worker(k):
         out = np.empty((H, W, 4), dtype=np.uint8)
+        import time
+
         start.wait()
-        for _ in range(40):
+        # (until this thread has had five reads of its own, a few hundred tries at most: a refused caller steps back for a
+        # moment, or the interpreter lock hands it its turns exactly while the other thread is inside the call)
+        for _ in range(400):
+            if results[k]["ok"] >= 5:
+                break
             out[:] = 0
             rc = lib.tr_read_rgba8_static(states[k]._ctx, out.ctypes.data, 1)  # (ctypes releases the GIL during the call)
             if rc == 0:
                 results[k]["ok" if np.array_equal(out, wants[k]) else "bad"] += 1
             elif rc == -7:  # TR_ERR_BUSY
                 results[k]["busy"] += 1
+                time.sleep(0.0007 * (1 + k))
             else:
                 results[k]["other"].append(rc)
 

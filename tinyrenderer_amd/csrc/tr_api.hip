@@ -113,6 +113,7 @@ struct tr_context {
     ScanRec* rec = nullptr;          // scanline records of the frame's first rec_cap slots
     uint32_t rec_cap = 1u << 20;     // 64 MB; slots beyond are rebuilt by every raster pass (TR_SCAN_RECORDS)
     bool rec_auto = true;            // grow with the first draw of a frame unless TR_SCAN_RECORDS pins the size
+    uint32_t* slots_seen = nullptr;  // page-locked word the winner pass leaves a frame's slot total in (never waited for)
     uint8_t* chunk_live = nullptr;
     uint32_t* flip_buf = nullptr;    // tr_read_rgba8(flip): the presented image, flipped on the device
     uint8_t* small_flag = nullptr;   // per triangle: rastered by k_small (tri_cap bytes)
@@ -420,6 +421,7 @@ void fill_raster_args(tr_context* c, RasterArgs& ra, uint32_t h_lo, uint32_t h_h
     ra.need_shade = c->deferred.empty() ? nullptr : c->need_shade;
     ra.mid_shift = mid_shift_for(h_hi - h_lo);
     ra.box = c->raster_box ? 1u : 0u;
+    ra.slots_seen = c->slots_seen;
     ra.view_tris = c->view_tris;
     ra.view_pix = (uint32_t)((size_t)c->W * c->H);
     ra.view_blk = c->blk_per_view;
@@ -480,6 +482,12 @@ int launch_scan(tr_context* c, uint32_t lo, uint32_t n_halves, const uint8_t* cu
 int grow_records_for(tr_context* c, uint64_t n_tris) {
     if (!(c->tri_total == 0 && c->rec_auto && c->mode != 1)) return TR_OK;
     uint64_t want = 8ull * n_tris;
+    // (large triangles take a slot per scanline, a hundred and more each: the slot total an earlier frame of this context
+    // left in `slots_seen` -- whichever was the last to get there, nobody waits for it -- plus a quarter)
+    if (c->slots_seen) {
+        const uint64_t seen = *(volatile uint32_t*)c->slots_seen;
+        if (seen + seen / 4 > want) want = seen + seen / 4;
+    }
     if (want > (64ull << 20)) want = 64ull << 20;  // 4 GB of records at most
     if (want > c->rec_cap) {
         TR_HIP(c, hipStreamSynchronize(c->stream));
@@ -929,6 +937,8 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (hipMemset2DAsync(c->blk_flags, 2, 0, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMemset2DAsync(c->blk_flags + 1, 2, 1, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->chunk_live, kChunkLiveCap) != hipSuccess) return bail(TR_ERR_OOM);
+    if (hipHostMalloc((void**)&c->slots_seen, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return bail(TR_ERR_OOM);
+    *c->slots_seen = 0u;
     if (hipMemsetAsync(c->chunk_live, 0, kChunkLiveCap, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->rec, (size_t)(c->rec_cap ? c->rec_cap : 1) * sizeof(ScanRec)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(TR_ERR_HIP);
@@ -949,7 +959,7 @@ void tr_destroy(tr_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->planes); (void)hipFree(c->rgba8); (void)hipFree(c->z_out); (void)hipFree(c->tri_out);
     (void)hipFree(c->rgba_f64); (void)hipFree(c->key_out); (void)hipFree(c->rast); (void)hipFree(c->shade); (void)hipFree(c->half_cnt);
-    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->small_grp); (void)hipFree(c->cluster_cull); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
+    (void)hipFree(c->half_off); (void)hipFree(c->rec); (void)hipFree(c->flip_buf); (void)hipFree(c->chunk_live); if (c->slots_seen) (void)hipHostFree(c->slots_seen); (void)hipFree(c->half_live); (void)hipFree(c->small_flag); (void)hipFree(c->need_shade); (void)hipFree(c->small_grp); (void)hipFree(c->cluster_cull); (void)hipFree(c->blk_flags); (void)hipFree(c->ticket);
     (void)hipFree(c->bin_cnt); (void)hipFree(c->bin_off); (void)hipFree(c->bin_list); (void)hipFree(c->refs); (void)hipFree(c->tile_sum); (void)hipFree(c->ndc); (void)hipFree(c->nout);
     (void)hipFree(c->draw_table); (void)hipFree(c->ext_table); (void)hipFree(c->state_both); (void)hipFree(c->nan_both);
     (void)hipFree(c->tile_cnt); (void)hipFree(c->tile_off); (void)hipFree(c->tile_list); (void)hipFree(c->pairs);

@@ -929,6 +929,8 @@ struct RasterArgs {
     uint32_t phase;             // k_small / k_mid depth pass: 0 every triangle, 1 the near ones only, 2 the far ones (kFlagFar) only
     uint32_t mid_shift;         // k_mid: log2 of the halves a wave looks up at once (0 .. 6)
     uint32_t box;               // k_raster depth pass: 1 = a chunk's samples are reduced in an LDS box of pixels first
+    uint32_t* slots_seen;       // winner pass: the slots of the range it ran over, left in host memory the GPU can write
+                                // (the context sizes the next frame's record buffer by it without ever waiting for it)
     int debug;                  // timing experiments only (TR_RASTER_DEBUG): 1 no atomics, 2 no loads either
     unsigned long long* trace;  // TR_RASTER_TRACE: 4 words per chunk (t_begin, t_records, t_end in 10 ns
                                 // ticks, samples | block << 32)
@@ -1144,6 +1146,7 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
     }
     bool nan_active = false;
     if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
+    if (PASS == 1 && a.slots_seen && blockIdx.x == 0 && threadIdx.x == 0) *a.slots_seen = s_end;
 
     for (uint32_t chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         if (PASS == 1 && chunk < a.live_cap) {
