@@ -937,8 +937,13 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (hipMemset2DAsync(c->blk_flags, 2, 0, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMemset2DAsync(c->blk_flags + 1, 2, 1, 1, c->n_blk, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->chunk_live, kChunkLiveCap) != hipSuccess) return bail(TR_ERR_OOM);
-    if (hipHostMalloc((void**)&c->slots_seen, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return bail(TR_ERR_OOM);
-    *c->slots_seen = 0u;
+    // (without it the record buffer is sized by the triangle count alone, as before: not an error)
+    if (hipHostMalloc((void**)&c->slots_seen, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        c->slots_seen = nullptr;
+    } else {
+        *c->slots_seen = 0u;
+    }
     if (hipMemsetAsync(c->chunk_live, 0, kChunkLiveCap, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->rec, (size_t)(c->rec_cap ? c->rec_cap : 1) * sizeof(ScanRec)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(TR_ERR_HIP);
