@@ -272,7 +272,10 @@ int tr_device_ptr_rgba8(tr_context* ctx, void** out_dev_ptr); /* u32[W*H], row-m
  * hipEvents on the context's stream when profiling is enabled:
  * [0] clear [1] transform [2] setup(+scan) [3] binning (tile mode) / depth pass (global mode)
  * [4] tile raster (tile mode) / winner pass (global mode) [5] shade;
- * counts[i] = number of launches accumulated. */
+ * counts[i] = number of launches accumulated.  A stage that is ONE kernel launch (the depth pass, the winner pass and
+ * the shade pass of a frame of ordinary triangles) is timed by that launch's own start / stop events
+ * (hipExtLaunchKernelGGL): the kernel's duration as a kernel trace reports it, without the 2-3 us that lie between an
+ * event recorded on the stream and the kernel's first wave. */
 int tr_profile_enable(tr_context* ctx, int enable);
 /* Shape of the last shade launch: out[0..2] = workgroups in x, y, z (z = views of a batch; all 0: nothing was
  * launched), out[3] = pixels per workgroup.  The RGBA8-only resolve launches the blocks of the frame's screen box

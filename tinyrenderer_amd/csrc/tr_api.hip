@@ -6,6 +6,8 @@
 #include "tr_tile.hip"
 #include "tr_rows.hip"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -207,6 +209,8 @@ struct tr_context {
     uint32_t scan_tag = 0;  // tag of the last fused k_setup launch (never 0 in a launch)
     bool prof = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;  // start / stop of a kernel launched with its own events (tr_profile_enable)
+    bool prof_kernel = false;                 // the open profiling scope was timed by ev2 / ev3: its one kernel, as rocprofv3 times it
     double prof_ms[ST_COUNT] = {0};
     uint64_t prof_n[ST_COUNT] = {0};
 };
@@ -251,6 +255,7 @@ struct ProfScope {
     tr_context* c;
     int stage;
     ProfScope(tr_context* c_, int s) : c(c_), stage(s) {
+        c->prof_kernel = false;
         if (c->prof) (void)hipEventRecord(c->ev0, c->stream);
     }
     ~ProfScope() {
@@ -258,12 +263,26 @@ struct ProfScope {
             (void)hipEventRecord(c->ev1, c->stream);
             (void)hipEventSynchronize(c->ev1);
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+            // (a stage that is ONE kernel is timed by that launch's own start / stop events: the kernel's duration as a
+            // kernel trace reports it, without the 2-3 us between an event on the stream and the kernel's first wave)
+            if (c->prof_kernel) (void)hipEventElapsedTime(&ms, c->ev2, c->ev3);
+            else (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
             c->prof_ms[stage] += ms;
             c->prof_n[stage] += 1;
         }
+        c->prof_kernel = false;
     }
 };
+// Launch of a stage's only kernel: with profiling on, through hipExtLaunchKernelGGL with the context's ev2 / ev3.
+#define TR_LAUNCH_STAGE(c, kernel, grid, block, ...)                                                              \
+    do {                                                                                                         \
+        if ((c)->prof) {                                                                                         \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, (c)->stream, (c)->ev2, (c)->ev3, 0, __VA_ARGS__);      \
+            (c)->prof_kernel = true;                                                                             \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL(kernel, grid, block, 0, (c)->stream, __VA_ARGS__);                                \
+        }                                                                                                        \
+    } while (0)
 
 // nalgebra's 4x4 * 4x4 (one gemv per result column, left-to-right accumulation); used for the
 // viewport matrix of src/model_renderer/mod.rs:314-318.
@@ -539,7 +558,7 @@ uint32_t* static_stage(int device) {
 inline std::atomic<int>& live_contexts(int device) { return g_live_contexts[device >= 0 && device < kMaxDevices ? device : 0]; }
 
 template <int PASS>
-void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block, hipStream_t stream, const RasterArgs& ra) {
+void launch_k_raster(tr_context* c, bool single, bool precheck, bool dbg, int threads, dim3 grid, dim3 block, hipStream_t stream, const RasterArgs& ra) {
     if (ra.view_tris) {  // a batch of views: the tuned settings only (filter in front of the depth atomics, none in front of the winner's)
         if (threads == 128) hipLaunchKernelGGL((k_raster<PASS, PASS == 0, false, 128, true>), grid, block, 0, stream, ra);
         else hipLaunchKernelGGL((k_raster<PASS, PASS == 0, false, 256, true>), grid, block, 0, stream, ra);
@@ -554,14 +573,25 @@ void launch_k_raster(bool precheck, bool dbg, int threads, dim3 grid, dim3 block
     }
 #endif
     (void)dbg;
+    // (`single`: this launch is all of its profiling stage -- timed by its own events when profiling is on)
     if (PASS == 0 && precheck) {
-        if (threads == 128) hipLaunchKernelGGL((k_raster_depth<128, TR_DEPTH_OCC_128>), grid, block, 0, stream, ra);
-        else hipLaunchKernelGGL((k_raster_depth<256, TR_DEPTH_OCC_256>), grid, block, 0, stream, ra);
+        if (single) {
+            if (threads == 128) TR_LAUNCH_STAGE(c, (k_raster_depth<128, TR_DEPTH_OCC_128>), grid, block, ra);
+            else TR_LAUNCH_STAGE(c, (k_raster_depth<256, TR_DEPTH_OCC_256>), grid, block, ra);
+        } else {
+            if (threads == 128) hipLaunchKernelGGL((k_raster_depth<128, TR_DEPTH_OCC_128>), grid, block, 0, stream, ra);
+            else hipLaunchKernelGGL((k_raster_depth<256, TR_DEPTH_OCC_256>), grid, block, 0, stream, ra);
+        }
         return;
     }
     if (PASS == 1 && !precheck) {
-        if (threads == 128) hipLaunchKernelGGL((k_raster_winner<128, TR_WINNER_OCC_128>), grid, block, 0, stream, ra);
-        else hipLaunchKernelGGL((k_raster_winner<256, TR_WINNER_OCC_256>), grid, block, 0, stream, ra);
+        if (single) {
+            if (threads == 128) TR_LAUNCH_STAGE(c, (k_raster_winner<128, TR_WINNER_OCC_128>), grid, block, ra);
+            else TR_LAUNCH_STAGE(c, (k_raster_winner<256, TR_WINNER_OCC_256>), grid, block, ra);
+        } else {
+            if (threads == 128) hipLaunchKernelGGL((k_raster_winner<128, TR_WINNER_OCC_128>), grid, block, 0, stream, ra);
+            else hipLaunchKernelGGL((k_raster_winner<256, TR_WINNER_OCC_256>), grid, block, 0, stream, ra);
+        }
         return;
     }
     if (threads == 128) { if (precheck) TR_LAUNCH(true, false, 128); else TR_LAUNCH(false, false, 128); }
@@ -634,7 +664,7 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
     }
     if (pass == 0) {
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
-        launch_k_raster<0>(c->precheck, dbg, threads, grid, block, c->stream, ra);
+        launch_k_raster<0>(c, !c->small_any && !c->mid_any && !rec_ready, c->precheck, dbg, threads, grid, block, c->stream, ra);
         // the sweeps of small / mid triangles in two launches when a draw of the frame split its triangles by depth
         // (kFlagFar): the near ones lower the plane, most samples of the far ones then fail the plain test
         const bool two = c->split_any && c->precheck;
@@ -661,7 +691,7 @@ int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool us
         // measured on MI355X (4K african_head): the winner pass is faster without the filter
         // (44 vs 52 us), the depth pass with it (71 vs 93 us)
         const bool dbg = ra.debug != 0 || ra.trace != nullptr;
-        launch_k_raster<1>(c->precheck_winner, dbg, threads, grid, block, c->stream, ra);
+        launch_k_raster<1>(c, !c->small_any && !c->mid_any, c->precheck_winner, dbg, threads, grid, block, c->stream, ra);
     }
     TR_HIP(c, hipGetLastError());
     return TR_OK;
@@ -947,6 +977,7 @@ int tr_create_views(int device, int width, int height, int max_views, tr_context
     if (hipMemsetAsync(c->chunk_live, 0, kChunkLiveCap, c->stream) != hipSuccess) return bail(TR_ERR_HIP);
     if (hipMalloc(&c->rec, (size_t)(c->rec_cap ? c->rec_cap : 1) * sizeof(ScanRec)) != hipSuccess) return bail(TR_ERR_OOM);
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(TR_ERR_HIP);
+    if (hipEventCreate(&c->ev2) != hipSuccess || hipEventCreate(&c->ev3) != hipSuccess) return bail(TR_ERR_HIP);
     if (ensure_tri_capacity(c, 16384) != TR_OK) return bail(TR_ERR_OOM);
     int rc = tr_clear(c);
     if (rc != TR_OK) return bail(rc);
@@ -975,6 +1006,8 @@ void tr_destroy(tr_context* c) {
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1869,8 +1902,8 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             }
         }
         else if (nothing) {}
-        else if (fast) hipLaunchKernelGGL((k_shade_fused<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
-        else hipLaunchKernelGGL((k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), 0, c->stream, sa);
+        else if (fast) TR_LAUNCH_STAGE(c, (k_shade_fused<false>), sgrid, dim3(kShadeBW * kShadeBH), sa);
+        else TR_LAUNCH_STAGE(c, (k_shade<false>), sgrid, dim3(kShadeBW * kShadeBH), sa);
         TR_HIP(c, hipGetLastError());
     }
     if (c->mode != 1 && out_mask == TR_OUT_RGBA8) {
