@@ -109,6 +109,28 @@ def _synthetic_component(obj, seed=3):
     return MeshComponent(obj, tex, nm)
 
 
+@pytest.mark.parametrize("nm_hw,tex_hw", [((2, 2), (2, 2)), ((3, 5), (3, 5)), ((1, 1), (1, 1)), ((5, 1), (5, 1)), ((1, 6), (1, 6)),
+                                          ((64, 64), (64, 64)), ((7, 7), (4, 9)), ((2, 2), (1, 1))])
+def test_texture_map_sizes_paired_and_not(oracle, nm_hw, tex_hw):
+    """`sample_nd_img` (helpers/mod.rs:253-278) on maps of every awkward size, through both texel paths of the fused shade
+    kernel: a normal map and a diffuse map of ONE size share indices and weights and are fetched together (width >= 2),
+    maps of different sizes -- and one-texel-wide ones -- are fetched one after the other.  The head's uv reach 0 and 1
+    exactly at some corners, i.e. the last column / row and their clamped neighbours."""
+    from tinyrenderer_amd.model_renderer import MeshComponent
+
+    rng = np.random.default_rng(nm_hw[0] * 131 + nm_hw[1] * 17 + tex_hw[0] * 7 + tex_hw[1])
+    head = SU.component("head")
+    mc = MeshComponent(head.mesh, rng.integers(0, 256, size=tex_hw + (4,), dtype=np.uint8),
+                       rng.integers(0, 256, size=nm_hw + (4,), dtype=np.uint8))
+    mc.transform.set_rotation((0.4, 0.1, 0.0))
+    W, Hh = 240, 170
+    draws = [(mc, scenes.shader_for(mc, W, Hh))]
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    g = SU.gpu_render(W, Hh, draws)
+    info = SU.assert_parity(o, g)
+    assert info["f64_colour_mismatches"] == 0 and info["covered"] > 5000
+
+
 def test_rando_triangle_face_normal_fallback(oracle):
     """helpers/mod.rs:558-608: one triangle, UVs, no normals -> face normal (mod.rs:245-258)."""
     from tinyrenderer_amd import helpers as H
