@@ -624,6 +624,16 @@ bool use_mid_path(const tr_context* c, uint64_t n_tris, uint64_t n_launch) {
     return n_launch >= 32768u && px_per_tri >= 16u && px_per_tri < (uint64_t)c->mid_px;
 }
 
+// Mean samples per slot the setup aims below when it spreads a triangle's scanlines over the slot sequence (k_setup), i.e.
+// half of what a 64-slot chunk holds at most.  Measured at 4K (african_head): a context that is alone on its device renders
+// fastest with chunks of <= 2 300 samples (36: 8 650 frames/s; 30: 8 570, 44: 8 310, 54: 8 210 -- one frame at a time the
+// launch's tail decides); with frames in flight on several contexts the chunks' fixed costs do, and larger chunks win
+// (36: 13 510 frames/s, 44: 13 680, 54: 13 830, 72: 13 780).
+#ifndef TR_SLOT_LEN_MANY
+#define TR_SLOT_LEN_MANY 54.0f
+#endif
+float slot_len_for(const tr_context* c) { return live_contexts(c->device).load() > 1 ? TR_SLOT_LEN_MANY : 36.0f; }
+
 // passes 0 / 1 over the half range [h_lo, h_hi)
 int launch_raster(tr_context* c, int pass, uint32_t h_lo, uint32_t h_hi, bool use_live = false, bool rec_ready = false) {
     RasterArgs ra;
@@ -1400,6 +1410,7 @@ int tr_draw_ext(tr_context* c, const tr_mesh* mesh, const tr_draw_params* p, con
         if (tri_base == 0 && c->draw_count == 0)
             c->frame_tiled = c->plane_tiles && (sa.mode & 4) && (c->W & 3) == 0 && (c->H & 1) == 0;
         sa.mid_samples = c->mid_samples;
+        sa.slot_len = slot_len_for(c);
         if (use_mid_path(c, (uint64_t)mesh->n_tris, (uint64_t)mesh->n_tris)) {
             sa.mode |= 16;  // triangles of up to 64 scanlines per half and a few hundred samples: one wave per half (k_mid)
             c->mid_any = true;
@@ -1609,6 +1620,7 @@ static int render_views_impl(tr_context* c, int n_meshes, const tr_mesh* const* 
             c->small_any = true;
         }
         sa.mid_samples = c->mid_samples;
+        sa.slot_len = slot_len_for(c);
         if (use_mid_path(c, per_view, total)) {
             sa.mode |= 16;  // triangles of up to 64 scanlines per half and a few hundred samples: one wave per half (k_mid)
             c->mid_any = true;

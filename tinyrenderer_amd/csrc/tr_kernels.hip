@@ -61,6 +61,7 @@ struct SetupArgs {
     int y_lo, y_hi;        // band of pixel rows owned by this context
     int mode;              // bit0: fill half_cnt, bit1: count tiles, bit2: flag small triangles (k_small), bit4: flag mid ones (k_mid),
                            // bit3: no TriShade now (k_build_shade writes it for the triangles the winner pass flags)
+    float slot_len;        // load balance of the slot sequence: a scanline gets slots until its mean length per slot is below this (k_setup)
     uint32_t mid_samples;  // mode bit 4: a triangle of at most 64 scanlines per half and about this many samples per half goes to k_mid
     uint32_t small_res;    // a triangle is small if neither half has more than small_res + 1 scanlines
     uint8_t* small_flag;   // per triangle: 1 = flagged kTriSmall (what k_small reads)
@@ -473,7 +474,8 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
             double ext = fmax(fabs(R.sp[0] - R.s1[0]), fabs(R.sp[1] - R.s1[1]));
             double mean_len = ext * 0.5 + 2.0;
             uint32_t sh = 0;
-            while (sh < 6u && mean_len >= 36.0) { mean_len *= 0.5; ++sh; }  // NaN: stays 0
+            const double slot_len = (double)a.slot_len;
+            while (sh < 6u && mean_len >= slot_len) { mean_len *= 0.5; ++sh; }  // NaN: stays 0
             R.slot_shift = sh;
         }
         // ---- conservative rect of tiles the triangle's samples can land in: every sample lies
