@@ -191,6 +191,36 @@ __device__ __forceinline__ int pixel_coord_raw(double v) {
     return r;
 }
 
+// Inclusive prefix sum of `v` over the 64 lanes of a wave in the VALU's data-parallel-primitive path: shifts within rows of 16
+// lanes by 1, 2, 4 and 8, then the last lane of rows 0 / 2 broadcast into rows 1 / 3 and the last lane of the lower half into the
+// upper half -- six adds, no LDS round trip (six `ds_bpermute` and their waits otherwise).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
+}
+
+// Minimum / maximum over each row of 16 lanes, left in every lane of the row (rotations within the row by 1, 2, 4 and 8).
+__device__ __forceinline__ int row16_min(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xf, 0xf, false));  // row_ror:1
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));
+    return x;
+}
+__device__ __forceinline__ int row16_max(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));
+    return x;
+}
+
 // The sample enumeration of one scanline end-point pair (segment_3d/mod.rs:26-33,41-48):
 // given the half's apex a1 and the two far ends a2 (short edge) and b2 (split point),
 // scanline i of `res` has A = a1 + t*(a2-a1), B = a1 + t*(b2-a1), t = i * (1/res).
@@ -198,10 +228,7 @@ struct Scanline {
     double ax, ay, az, dx, dy, dz;  // A and B-A
     uint32_t hres;                  // horizontal resolution (>= 2), or kBig+1 if too long
 };
-__device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t half, uint32_t i, double delta) {
-    const double* a1 = half ? r.s2 : r.s0;
-    const double* a2 = r.s1;
-    const double* b2 = r.sp;
+__device__ __forceinline__ Scanline make_scanline_pts(const double* a1, const double* a2, const double* b2, uint32_t i, double delta) {
     double t = (double)i * delta;
     double Ax = a1[0] + t * (a2[0] - a1[0]);
     double Ay = a1[1] + t * (a2[1] - a1[1]);
@@ -220,6 +247,9 @@ __device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t h
     else h = (uint32_t)c + 1u;
     s.hres = h < 2u ? 2u : h;
     return s;
+}
+__device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t half, uint32_t i, double delta) {
+    return make_scanline_pts(half ? r.s2 : r.s0, r.s1, r.sp, i, delta);
 }
 __device__ __forceinline__ Scanline make_scanline(const TriRaster& r, uint32_t half, uint32_t i) {
     return make_scanline(r, half, i, 1.0 / (double)r.res[half]);

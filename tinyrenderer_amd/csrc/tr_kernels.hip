@@ -210,12 +210,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
     __shared__ uint32_t s_wtot[4];
     __shared__ unsigned long long s_base;
     const uint32_t pair = c0 + c1;  // (< 2^25)
-    uint32_t inc = pair;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;  // (< 2^31)
-    }
+    const uint32_t inc = wave_inclusive_sum(pair);  // (< 2^31)
     if (lane == 63) s_wtot[wave] = inc;
     __syncthreads();
     unsigned long long before = 0, tot = 0;
@@ -631,12 +626,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total_
     // exclusive scan of one value per thread across a 256-thread block
     __shared__ uint32_t wsum[kScanThreads / 64];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
+    const uint32_t inc = wave_inclusive_sum(v);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
@@ -1124,7 +1114,7 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
     // (32-bit while they are being added to: flushed to the 64-bit counters before they can wrap)
     uint32_t cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
     auto flush_counts = [&]() {
-        uint32_t cs = (uint32_t)__shfl((int)cnt_samples, 0, 64), ci = (uint32_t)__shfl((int)cnt_inb, 0, 64), sc = cnt_scan;
+        uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)cnt_samples, 0), ci = (uint32_t)__builtin_amdgcn_readlane((int)cnt_inb, 0), sc = cnt_scan;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) sc += __shfl_down(sc, d, 64);
         if ((threadIdx.x & 63) == 0 && (cs | sc)) {
@@ -1225,18 +1215,11 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
             }
         }
         __syncthreads();
-        uint32_t cnt = 0;
         if (wave0) {
+            // (wave scans and row reductions of this prologue in the VALU's DPP path, not through `ds_bpermute`: they sit on every
+            // chunk's serial stretch -- 4K depth pass 52.5 -> 50.3 us, winner pass 27.2 -> 26.0 us)
             const uint32_t h = (uint32_t)(sRecU[lane * 8 + 7] & kRecHresMask);
-            cnt = h ? h + 1u : 0u;
-        }
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += t;
-        }
-        if (wave0) {
+            const uint32_t inc = wave_inclusive_sum(h ? h + 1u : 0u);
             sPre[lane + 1] = inc;
             if (lane == 0) sPre[0] = 0;
             if (VIEWS) sView[lane] = (uint32_t)(sRecU[lane * 8 + 7] >> kKeyTriShift) / a.view_tris;  // (an empty slot: view 0, never read)
@@ -1257,6 +1240,9 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
                 const int yl = max(min(ya, yb), a.y_lo), yh = min(max(ya, yb), a.y_hi - 1);
                 if (xl <= xh && yl <= yh) { x_lo = xl; x_hi = xh; y_lo = yl; y_hi = yh; }
             }
+            if (kBoxSubShift == 4) {
+                x_lo = row16_min(x_lo); y_lo = row16_min(y_lo); x_hi = row16_max(x_hi); y_hi = row16_max(y_hi);
+            } else
 #pragma unroll
             for (int d = 1; d < (1 << kBoxSubShift); d <<= 1) {
                 x_lo = min(x_lo, __shfl_xor(x_lo, d, 64));
@@ -1270,16 +1256,11 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
             const bool has = w != 0u && h != 0u;
             const bool fits = has && w <= 1024u && (unsigned long long)w * h <= (unsigned long long)kBoxPix;
             const uint32_t n = leader && fits ? w * h : 0u;
-            uint32_t incl = n;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
-            }
+            const uint32_t incl = wave_inclusive_sum(n);
             const bool boxed = fits && incl <= (uint32_t)kBoxPix;
             const unsigned long long m_boxed = __ballot(leader && boxed);
             const unsigned long long m_open = __ballot(leader && has && !boxed);
-            const uint32_t used = m_boxed ? (uint32_t)__shfl((int)incl, 63 - __builtin_clzll(m_boxed), 64) : 0u;
+            const uint32_t used = m_boxed ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 63 - __builtin_clzll(m_boxed)) : 0u;
             if (leader) {
                 const int b = lane >> kBoxSubShift;
                 sBoxA[b] = make_uint4((uint32_t)x_lo, (uint32_t)y_lo, boxed ? (w | (h << 16)) : 0u, incl - n);
@@ -1495,7 +1476,7 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
             t[0] = tr_t0; t[1] = tr_t1; t[2] = wall_clock64();
             t[3] = (unsigned long long)total | ((unsigned long long)blockIdx.x << 32);
         }
-        if (PASS == 0 && (uint32_t)__shfl((int)cnt_samples, 0, 64) > 0x40000000u) flush_counts();  // (uniform per wave)
+        if (PASS == 0 && (uint32_t)__builtin_amdgcn_readlane((int)cnt_samples, 0) > 0x40000000u) flush_counts();  // (uniform per wave)
         if (threadIdx.x == 0 && chunk < a.live_cap) {
             if (PASS == 0) {
                 if (live) a.chunk_live[chunk] = 1;
@@ -1718,7 +1699,7 @@ template <int PASS, bool PRECHECK>
 // cap on k_small<0>, 68 VGPRs, spills and changes nothing for the 10^7-triangle frame.)
 __global__ __launch_bounds__(64 * kMidWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_mid(RasterArgs a, uint8_t* half_live) {
     __shared__ double sRec[kMidWaves][64][7];      // A, B - A, 1 / hres of the half's scanlines
-    __shared__ uint32_t sPre[kMidWaves][65];       // exclusive prefix of their sample counts
+    __shared__ __align__(16) uint32_t sPre[kMidWaves][68];  // exclusive prefix of their sample counts ([64] = total; rows of 17 x 16 bytes)
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t wave_id = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long cnt_samples = 0, cnt_inb = 0, cnt_scan = 0;
@@ -1748,44 +1729,60 @@ __global__ __launch_bounds__(64 * kMidWaves) __attribute__((amdgpu_waves_per_eu(
         const uint32_t h = blk * bn + (uint32_t)__builtin_ctzll(todo);  // (the same for every lane)
         todo &= todo - 1ull;
         const uint32_t tri = h >> 1, half = h & 1u;
-        const TriRaster& t = a.rast[tri];
-        const uint32_t res = t.res[half];  // (2 .. 63)
+        // (the half is the same for every lane: its record comes through the scalar cache into scalar registers -- k_setup wrote it
+        // in an earlier launch; 24 fewer VGPRs and no vector-memory round trip ahead of the scanlines: 30.4 -> 30.9 k orbit views/s)
+        const auto* tp = reinterpret_cast<const __attribute__((address_space(4))) TriRaster*>((uintptr_t)(a.rast + tri));
+        const double t_a1[3] = {half ? tp->s2[0] : tp->s0[0], half ? tp->s2[1] : tp->s0[1], half ? tp->s2[2] : tp->s0[2]};
+        const double t_a2[3] = {tp->s1[0], tp->s1[1], tp->s1[2]}, t_b2[3] = {tp->sp[0], tp->sp[1], tp->sp[2]};
+        const uint32_t res = half ? tp->res[1] : tp->res[0];  // (2 .. 63)
         const bool counted = h >= a.count_h;
         const uint32_t vw = a.view_tris ? tri / a.view_tris : 0u;
         const uint32_t pix_base = vw * a.view_pix, blk_base = vw * a.view_blk;
         lds_sync();  // the previous half's readers are done with the wave's corner of LDS
         uint32_t cnt = 0;
         if (lane <= res) {
-            const Scanline sl = make_scanline(t, half, lane, 1.0 / (double)res);
+            const Scanline sl = make_scanline_pts(t_a1, t_a2, t_b2, lane, 1.0 / (double)res);
             double* r = sRec[w][lane];
             r[0] = sl.ax; r[1] = sl.ay; r[2] = sl.az; r[3] = sl.dx; r[4] = sl.dy; r[5] = sl.dz;
             r[6] = 1.0 / (double)sl.hres;
             cnt = sl.hres + 1u;  // (k_setup bounds res <= 63 and the half's estimated samples (mid_samples), not hres: a thin half may have hres in
                                  // the thousands; the 32-bit prefix and the key's 18-bit j field hold it)
         }
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 64);
-            if ((int)lane >= d) inc += up;
-        }
+        // (the wave scan in the VALU's DPP path and the total from a lane read: no LDS round trips ahead of the sample rounds --
+        // with `__shfl_up`, six dependent `ds_bpermute`, the orbit's winner pass took 207 instead of 189 us per batch of 32 views)
+        const uint32_t inc = wave_inclusive_sum(cnt);
         sPre[w][lane + 1] = inc;
         if (lane == 0) sPre[w][0] = 0;
         lds_sync();
-        const uint32_t total = sPre[w][64];
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         if (PASS == 0 && counted) {
             cnt_scan += lane == 0 ? res + 1u : 0u;
             cnt_samples += lane == 0 ? total : 0u;
         }
         bool live = false;
+        // first samples of scanlines 8, 16, .., 56 (the inclusive sums of lanes 7, 15, ..): the same for every lane, scalar registers
+        const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 7), g2 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15),
+                       g3 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 23), g4 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31),
+                       g5 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 39), g6 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 47),
+                       g7 = (uint32_t)__builtin_amdgcn_readlane((int)inc, 55);
         for (uint32_t k0 = 0; k0 < total; k0 += 64u) {
             const uint32_t k = k0 + lane;
             if (k >= total) continue;  // (only in the last round)
-            uint32_t sidx = 0;  // the last scanline whose first sample is <= k
-#pragma unroll
-            for (uint32_t step = 32; step; step >>= 1)
-                if (sPre[w][sidx + step] <= k) sidx += step;
-            const uint32_t j = k - sPre[w][sidx];
+            // the last scanline whose first sample is <= k: its group of 8 from the uniform values, the group's 8 prefix entries
+            // in two 16-byte LDS reads, a selection tree in registers -- one LDS round trip instead of six dependent ones (k_raster's search)
+            const bool c4 = g4 <= k;
+            const bool c2 = (c4 ? g6 : g2) <= k;
+            const bool c1 = (c4 ? (c2 ? g7 : g5) : (c2 ? g3 : g1)) <= k;
+            const uint32_t grp = (c4 ? 4u : 0u) + (c2 ? 2u : 0u) + (c1 ? 1u : 0u);
+            const uint4 ea = *reinterpret_cast<const uint4*>(&sPre[w][8u * grp]);
+            const uint4 eb = *reinterpret_cast<const uint4*>(&sPre[w][8u * grp + 4u]);
+            const bool d4 = eb.x <= k;
+            const uint32_t a0 = d4 ? eb.x : ea.x, a1 = d4 ? eb.y : ea.y, a2 = d4 ? eb.z : ea.z, a3 = d4 ? eb.w : ea.w;
+            const bool d2 = a2 <= k;
+            const uint32_t b0 = d2 ? a2 : a0, b1 = d2 ? a3 : a1;
+            const bool d1 = b1 <= k;
+            const uint32_t sidx = 8u * grp + (d4 ? 4u : 0u) + (d2 ? 2u : 0u) + (d1 ? 1u : 0u);
+            const uint32_t j = k - (d1 ? b1 : b0);
             const double* r = sRec[w][sidx];
             const double sp = (double)j * r[6];
             const double x = r[0] + sp * r[3];
