@@ -1089,6 +1089,8 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
     __shared__ uint32_t sBoxMagic[kBoxOn ? kBoxSubs : 1];  // per box: 2^21 / width + 1
     __shared__ uint32_t sBoxEnd[kBoxOn ? kBoxSubs : 1];    // per box: one past its last entry
     __shared__ uint32_t sBoxHdr[2];                        // entries in use, 1 = some samples of the chunk are not boxed
+    __shared__ uint32_t sLive[2];                          // depth pass: a sample of the chunk reached the plane's value (per chunk parity)
+    if (threadIdx.x == 0) { sLive[0] = 0u; sLive[1] = 0u; }
     const bool box_on = kBoxOn && a.box != 0;
     if (box_on)
         for (uint32_t p = threadIdx.x; p < (uint32_t)kBoxPix; p += (uint32_t)kRasterThreads) sBox[p] = ~0ull;
@@ -1140,6 +1142,7 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
     if (PASS == 1) nan_active = a.nan->pix[0] != kNanEmpty;
     if (PASS == 1 && a.slots_seen && blockIdx.x == 0 && threadIdx.x == 0) *a.slots_seen = s_end;
 
+    uint32_t n_voted = 0;
     for (uint32_t chunk = c_lo + blockIdx.x; chunk < c_hi; chunk += gridDim.x) {
         if (PASS == 1 && chunk < a.live_cap) {
             // a chunk none of whose samples reached the depth plane's value cannot hold a winner
@@ -1469,8 +1472,17 @@ __device__ __forceinline__ void raster_body(const RasterArgs& a) {
                 }
             }
         }
-        // (also the barrier before the next chunk rewrites LDS)
-        const int live = __syncthreads_or(any_live ? 1 : 0);
+        // One barrier (also the one before the next chunk rewrites LDS), and for the depth pass the chunk's "live" vote through
+        // a word of LDS per chunk parity (`__syncthreads_or` is three barriers and three LDS operations; the word a chunk
+        // uses is zeroed by thread 0 a chunk ahead, after it has read the word's previous value and barriers before anyone writes it again)
+        int live = 0;
+        const uint32_t par = n_voted++ & 1u;  // (votes this workgroup has held: uniform)
+        if (PASS == 0) {
+            if (threadIdx.x == 0) sLive[par ^ 1u] = 0u;
+            if (__ballot(any_live) != 0ull && lane == 0) sLive[par] = 1u;
+        }
+        __syncthreads();
+        if (PASS == 0 && threadIdx.x == 0) live = (int)sLive[par];
         if (dbg_trace && threadIdx.x == 0 && chunk - c_lo < a.trace_cap) {
             unsigned long long* t = dbg_trace + 4 * (size_t)(chunk - c_lo);
             t[0] = tr_t0; t[1] = tr_t1; t[2] = wall_clock64();
