@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
         }
         a.half_cnt[2 * (size_t)(a.tri_base + g)] = c0;  // (setup_triangle leaves the counts to its caller when `fused`)
         a.half_cnt[2 * (size_t)(a.tri_base + g) + 1] = c1;
+        // (the triangle's view, for k_mid: a scalar load there instead of a 32-bit division per half; after setup_triangle's
+        // own store of the record, by the same thread)
+        a.rast[a.tri_base + g].pad[0] = view;
         return;
     }
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1748,7 +1751,7 @@ __global__ __launch_bounds__(64 * kMidWaves) __attribute__((amdgpu_waves_per_eu(
         const double t_a2[3] = {tp->s1[0], tp->s1[1], tp->s1[2]}, t_b2[3] = {tp->sp[0], tp->sp[1], tp->sp[2]};
         const uint32_t res = half ? tp->res[1] : tp->res[0];  // (2 .. 63)
         const bool counted = h >= a.count_h;
-        const uint32_t vw = a.view_tris ? tri / a.view_tris : 0u;
+        const uint32_t vw = a.view_tris ? tp->pad[0] : 0u;  // (k_setup<.., VIEWS> left the view there: tri / view_tris)
         const uint32_t pix_base = vw * a.view_pix, blk_base = vw * a.view_blk;
         lds_sync();  // the previous half's readers are done with the wave's corner of LDS
         uint32_t cnt = 0;
