@@ -56,7 +56,8 @@ struct __attribute__((aligned(256))) TriShade {
     double t[3], b[3];    // tangent / bitangent xyz (mod.rs:346-351)
     uint32_t draw;        // index into the per-frame draw table
     uint32_t flags;       // bit0 has_uv (all three corners), bit1 has_tb
-    uint32_t pad[4];
+    double inv_res[2];    // 1.0 / res[half] of the triangle's TriRaster (mod.rs:376: `delta`): the same division, done once per
+                          // triangle at setup instead of once per shaded pixel
 };
 static_assert(sizeof(TriShade) == 256, "TriShade must be 256 B");
 

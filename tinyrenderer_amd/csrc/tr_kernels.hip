@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_setup(SetupArgs a) {
 __device__ __forceinline__ TriShade make_shade_record(const SetupArgs& a, const uint32_t iv[3], const uint32_t it[3],
                                                       const uint32_t in[3], const double px[3], const double py[3],
                                                       const double pz[3], const double vx[3], const double vy[3],
-                                                      bool fused, const Mat4& nmat, uint32_t draw) {
+                                                      bool fused, const Mat4& nmat, uint32_t draw, uint32_t res0, uint32_t res1) {
     TriShade S;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -341,7 +341,8 @@ __device__ __forceinline__ TriShade make_shade_record(const SetupArgs& a, const 
     }
     S.draw = draw;
     S.flags = fl;
-    S.pad[0] = S.pad[1] = S.pad[2] = S.pad[3] = 0;
+    S.inv_res[0] = 1.0 / (double)res0;  // (res 0: a half without scanlines, never read)
+    S.inv_res[1] = 1.0 / (double)res1;
     return S;
 }
 
@@ -461,7 +462,7 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
             }
         }
         // ---- shade record: now, or (mode bit 3) after the winner pass and only for triangles that may own a pixel
-        if (!(a.mode & 8)) a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, fused, nmat, draw);
+        if (!(a.mode & 8)) a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, fused, nmat, draw, res0, res1);
         R.res[0] = res0;
         R.res[1] = res1;
         // Load balance of the global raster: a chunk is 64 slots.  A triangle whose scanlines are
@@ -585,7 +586,8 @@ __device__ __forceinline__ void build_shade_record(const SetupArgs& a, uint32_t 
         vx[c] = g[0] / g[3];
         vy[c] = g[1] / g[3];
     }
-    a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, true, a.nmat, a.draw);
+    const uint32_t res0 = a.rast[seq].res[0], res1 = a.rast[seq].res[1];  // (k_setup's, written a launch ago)
+    a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, true, a.nmat, a.draw, res0, res1);
 }
 
 // Bounding boxes of the mesh's clusters of 64 consecutive triangles (object space), once per mesh (tr_mesh_create):
@@ -2222,9 +2224,9 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
         staged = todo == 0ull && n_dist != 0u;  // (uniform)
         if (staged) {
             __syncthreads();  // (one wave: orders the list's writes before its reads)
-            // 16-byte chunks per triangle: the first 7 of TriRaster (points, split point, res) and the first 14 of TriShade
-            // (everything but the padding)
-            constexpr uint32_t kRastChunks = 7u, kChunks = 21u;
+            // 16-byte chunks per triangle: the first 7 of TriRaster (points, split point, res) and the first 15 of TriShade
+            // (all but its last 16 bytes, which are alignment)
+            constexpr uint32_t kRastChunks = 7u, kChunks = 22u;
             const uint32_t n_chunks = n_dist * kChunks;
 #pragma unroll
             for (uint32_t c0 = 0; c0 < (uint32_t)kStageTris * kChunks; c0 += 64u) {
@@ -2248,7 +2250,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
         uint32_t i = (uint32_t)(key >> kKeyIShift) & 0x1FFFFu;
         uint32_t j = (uint32_t)key & 0x3FFFFu;
       auto shade_px = [&](const TriRaster& r, const TriShade& s) __attribute__((always_inline)) {
-        Scanline sl = make_scanline(r, half, i);
+        Scanline sl = make_scanline(r, half, i, s.inv_res[half]);  // (delta = 1 / res from the record: one division less per pixel)
         double sp = (double)j * (1.0 / (double)sl.hres);
         double px = sl.ax + sp * sl.dx;
         double py = sl.ay + sp * sl.dy;
