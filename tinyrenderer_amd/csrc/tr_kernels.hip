@@ -1967,17 +1967,20 @@ __device__ __forceinline__ Taps sample_taps(const uint32_t* __restrict__ img, in
         // column min(ix1, W - 2) (the texture unit spends its cycles per wave-instruction, not per byte: PMC)
         struct __attribute__((packed, aligned(4))) Pair { uint32_t lo, hi; };
         const uint32_t bx = ix1 < (uint32_t)(W - 1) ? ix1 : (uint32_t)(W - 2);
-        const Pair r1 = *reinterpret_cast<const Pair*>(img + (size_t)iy1 * W + bx);
-        const Pair r2 = *reinterpret_cast<const Pair*>(img + (size_t)iy2 * W + bx);
+        // (32-bit byte offsets: a texture is at most 32768 x 32768 texels = 2^32 bytes, tr_texture_create; the base is the same in
+        // every lane as a rule, so the load takes it from scalar registers and the address costs no 64-bit arithmetic)
+        const char* base = reinterpret_cast<const char*>(img);
+        const Pair r1 = *reinterpret_cast<const Pair*>(base + (iy1 * (uint32_t)W + bx) * 4u);
+        const Pair r2 = *reinterpret_cast<const Pair*>(base + (iy2 * (uint32_t)W + bx) * 4u);
         t.c00 = ix1 == bx ? r1.lo : r1.hi;
         t.c10 = ix2 == bx ? r1.lo : r1.hi;
         t.c01 = ix1 == bx ? r2.lo : r2.hi;
         t.c11 = ix2 == bx ? r2.lo : r2.hi;
     } else {
-        t.c00 = img[(size_t)iy1 * W + ix1];
-        t.c10 = img[(size_t)iy1 * W + ix2];
-        t.c01 = img[(size_t)iy2 * W + ix1];
-        t.c11 = img[(size_t)iy2 * W + ix2];
+        t.c00 = img[iy1 * (uint32_t)W + ix1];
+        t.c10 = img[iy1 * (uint32_t)W + ix2];
+        t.c01 = img[iy2 * (uint32_t)W + ix1];
+        t.c11 = img[iy2 * (uint32_t)W + ix2];
     }
     t.w00 = (x2 - x) * (y2 - y);
     t.w10 = (x - x1) * (y2 - y);
@@ -2007,11 +2010,14 @@ __device__ __forceinline__ void sample_taps_pair(const uint32_t* __restrict__ im
     }
     struct __attribute__((packed, aligned(4))) Pair { uint32_t lo, hi; };
     const uint32_t bx = ix1 < (uint32_t)(W - 1) ? ix1 : (uint32_t)(W - 2);  // (W >= 2: the caller checked)
-    const size_t o1 = (size_t)iy1 * W + bx, o2 = (size_t)iy2 * W + bx;
-    const Pair a1 = *reinterpret_cast<const Pair*>(img_a + o1);
-    const Pair a2 = *reinterpret_cast<const Pair*>(img_a + o2);
-    const Pair b1 = *reinterpret_cast<const Pair*>(img_b + o1);
-    const Pair b2 = *reinterpret_cast<const Pair*>(img_b + o2);
+    // (32-bit byte offsets, as in sample_taps)
+    const uint32_t o1 = (iy1 * (uint32_t)W + bx) * 4u, o2 = (iy2 * (uint32_t)W + bx) * 4u;
+    const char* base_a = reinterpret_cast<const char*>(img_a);
+    const char* base_b = reinterpret_cast<const char*>(img_b);
+    const Pair a1 = *reinterpret_cast<const Pair*>(base_a + o1);
+    const Pair a2 = *reinterpret_cast<const Pair*>(base_a + o2);
+    const Pair b1 = *reinterpret_cast<const Pair*>(base_b + o1);
+    const Pair b2 = *reinterpret_cast<const Pair*>(base_b + o2);
     const bool l1 = ix1 == bx, l2 = ix2 == bx;
     ta.c00 = l1 ? a1.lo : a1.hi;
     ta.c10 = l2 ? a1.lo : a1.hi;
