@@ -385,14 +385,22 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
     if (cull && (a.mode & 2)) a.rast[seq] = R;  // (only the tile raster's binning pass reads the record of every triangle)
     if (!cull) {
         // mod.rs:320-327 viewport transform; w of the product is 1 unless inputs are non-finite.
-        double vx[3], vy[3], vz[3];
+        // (the viewport matrix's last row is 0 0 0 1, so w is exactly 1 unless a coordinate is not finite -- 0 * inf --, and
+        // x / 1.0 is x bit for bit: the nine divisions are done only by a wave that holds such a corner)
+        double vx[3], vy[3], vz[3], vw[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double g[4];
             mat4_mul_vec4(a.vpm, px[c], py[c], pz[c], 1.0, g);
-            vx[c] = g[0] / g[3];
-            vy[c] = g[1] / g[3];
-            vz[c] = g[2] / g[3];
+            vx[c] = g[0]; vy[c] = g[1]; vz[c] = g[2]; vw[c] = g[3];
+        }
+        if (!__all(vw[0] == 1.0 && vw[1] == 1.0 && vw[2] == 1.0)) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                vx[c] = vx[c] / vw[c];
+                vy[c] = vy[c] / vw[c];
+                vz[c] = vz[c] / vw[c];
+            }
         }
         // A context that owns a band of rows (multi-GPU, tr_set_band): a triangle none of whose samples
         // can land in the band (every sample lies in the hull of the corners up to a few ulp and lands
@@ -574,7 +582,7 @@ __device__ __forceinline__ void build_shade_record(const SetupArgs& a, uint32_t 
     const uint32_t iv[3] = {ix[0], ix[3], ix[6]};
     const uint32_t it[3] = {ix[1], ix[4], ix[7]};
     const uint32_t in[3] = {ix[2], ix[5], ix[8]};
-    double px[3], py[3], pz[3], vx[3], vy[3];
+    double px[3], py[3], pz[3], vx[3], vy[3], vw[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         double g[4];
@@ -583,8 +591,14 @@ __device__ __forceinline__ void build_shade_record(const SetupArgs& a, uint32_t 
         py[c] = g[1] / g[3];
         pz[c] = g[2] / g[3];
         mat4_mul_vec4(a.vpm, px[c], py[c], pz[c], 1.0, g);  // mod.rs:320-327
-        vx[c] = g[0] / g[3];
-        vy[c] = g[1] / g[3];
+        vx[c] = g[0]; vy[c] = g[1]; vw[c] = g[3];
+    }
+    if (!__all(vw[0] == 1.0 && vw[1] == 1.0 && vw[2] == 1.0)) {  // (w is exactly 1 for finite corners: setup_triangle)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            vx[c] = vx[c] / vw[c];
+            vy[c] = vy[c] / vw[c];
+        }
     }
     const uint32_t res0 = a.rast[seq].res[0], res1 = a.rast[seq].res[1];  // (k_setup's, written a launch ago)
     a.shade[seq] = make_shade_record(a, iv, it, in, px, py, pz, vx, vy, true, a.nmat, a.draw, res0, res1);
