@@ -186,6 +186,36 @@ def test_nan_depth_degenerate_triangle(oracle):
                 assert np.isnan(o["z"][0, 0]) == (order[0] is d)
 
 
+def test_non_finite_corners(oracle):
+    """Corners the perspective divide sends to infinity or NaN (clip w = 0: a vertex on the camera plane).  The reference has
+    no clipping: such a triangle is kept when another corner is inside (mod.rs:293-312), its viewport points are NaN
+    (0 * inf in the viewport product's w: the one case in which that w is not exactly 1, and k_setup divides by it), its
+    scanlines and samples follow the NaN rules (sort: partial_cmp -> Equal, `as` casts -> 0), and it may leave NaN at pixel (0, 0)."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    N = H.NONE_INDEX
+    # clip = (x, y, z, z): w = z
+    P = np.array([[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 1.0, 0], [0, 0, 1.0, 0]])
+    wild = H.Object([[0.3, 0.2, 0.0], [0.1, 0.1, 0.5], [-0.2, 0.1, 0.5],        # first corner: (inf, inf, NaN)
+                     [0.0, 0.0, 0.0], [0.2, -0.1, 0.5], [-0.1, -0.2, 0.5],      # first corner: 0 / 0 throughout
+                     [0.2, 0.1, 0.5], [-0.3, -0.2, 0.0], [0.1, -0.3, 0.5]],     # middle corner: (-inf, -inf, NaN)
+                    [[0.1, 0.2, 0], [0.9, 0.3, 0], [0.4, 0.95, 0]], [[0, 0, 1]],
+                    [[0, 0, 0, 1, 1, 0, 2, 2, 0], [3, 0, 0, 4, 1, 0, 5, 2, 0], [6, 0, 0, 7, 1, 0, 8, 2, 0]])
+    tame = H.Object([[-0.4, -0.4, 0.5], [0.4, -0.4, 0.5], [-0.4, 0.4, 0.5]], np.zeros((0, 3)), np.zeros((0, 3)),
+                    [[0, N, N, 1, N, N, 2, N, N]])
+    w_, t_ = _synthetic_component(wild), _synthetic_component(tame)
+    sh = BuiltinShader(P, np.eye(4), (0.0, 0.0, 2.0))
+    for order in ((w_, t_), (t_, w_), (w_,)):
+        for mode in (2, 1, 0):
+            for W, Hh in ((24, 24), (64, 48)):
+                draws = [(mc, sh) for mc in order]
+                o = SU.oracle_render(oracle, W, Hh, draws)
+                g = SU.gpu_render(W, Hh, draws, mode=mode)
+                SU.assert_parity(o, g)
+    assert o["counters"]["culled"] == 0
+
+
 def test_offscreen_and_culled(oracle):
     """Triangles partly / fully outside the frustum: per-corner cull (mod.rs:293-312) and the
     bounds test (mod.rs:380-386); no clipping exists in the reference."""
