@@ -14,7 +14,8 @@
 // so the Rust binary cannot be run.  This oracle is pinned by (a) the
 // known-answer tests derived by hand from the cited source lines
 // (tests/test_oracle_kat.py), (b) the one output artefact the reference holds,
-// sample.jpg (README.md:5, a lossy 2160x3840 JPEG of the loop's first frame):
+// sample.jpg (README.md:5, a lossy 2160x3840 JPEG of the scene with the head's
+// rotation at 0):
 // at full resolution the oracle's presented image differs from it by 1.24 LSB
 // on average over the 4.8 M covered pixels (99 % within 4 LSB, silhouettes
 // differ on 0.13 % of the frame), and a shift by one pixel, a turn of the head

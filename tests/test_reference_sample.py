@@ -5,7 +5,7 @@ pin bits.  What it does pin:
 * coarse (270x480, normalised correlation): projection, winding / z order, texture orientation, tangent-space
   normal mapping, lighting -- the oracle's frame correlates with it at 0.99+, visibly wrong variants do not;
 * at FULL resolution (2160x3840, the literals of src/main.rs:62-70,110-142 with the head's rotation at 0, i.e. the
-  loop's first frame): over the 4.8 M covered pixels the oracle's presented image differs from the JPEG by 1.24 LSB
+  scene at rest -- the angle was found by scanning it; the loop itself draws its first frame at 0.025 rad): over the 4.8 M covered pixels the oracle's presented image differs from the JPEG by 1.24 LSB
   on average (median 1, 99 % within 4 LSB, 99.7 % within 8 LSB on every channel -- the JPEG's own quantisation noise,
   with its chroma bias of +1.2 in R and B), the silhouettes disagree on 0.13 % of the frame, and every one of the
   following makes it measurably worse: the frame shifted by ONE pixel in any direction (1.43-1.46), the head turned by
