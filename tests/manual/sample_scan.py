@@ -4,14 +4,14 @@ resolution: scans the head's rotation (the one parameter the screenshot does not
 absolute difference over the covered pixels, its percentiles and the share of the frame on which the silhouettes disagree;
 then one-pixel shifts, the normal map left out and the vertical flip at the best angle.  CPU only (oracle/, test
 infrastructure).  The numbers quoted in DESIGN.md 5 and asserted by tests/test_reference_sample.py come from here.
-    python tools/sample_scan.py [angle ...]        (default: -0.005 -0.002 -0.001 0 0.001 0.002 0.005 0.0125 0.025)"""
+    python tests/manual/sample_scan.py [angle ...]        (default: -0.005 -0.002 -0.001 0 0.001 0.002 0.005 0.0125 0.025)"""
 import os
 import sys
 
 import numpy as np
 from PIL import Image
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_ffi  # noqa: E402
