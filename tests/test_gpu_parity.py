@@ -323,6 +323,63 @@ def test_band_sharding_is_exact(oracle):
         assert frags == full["counters"]["fragments"]
 
 
+def _assert_bands_stitch_to(o, W, Hh, draws, edges, mode):
+    """Every band [edges[k], edges[k + 1]) rendered by itself; the stitched planes must be the oracle's whole frame."""
+    z = np.full_like(o["z"], -np.inf)
+    key = np.full_like(o["key"], np.uint64(0xFFFFFFFFFFFFFFFF))
+    present = np.zeros_like(o["present"])
+    frags = 0
+    for y_lo, y_hi in zip(edges[:-1], edges[1:]):
+        g = SU.gpu_render(W, Hh, draws, mode=mode, band=(y_lo, y_hi))
+        assert g["flags"] == 0
+        z[:, y_lo:y_hi] = g["z"][:, y_lo:y_hi]
+        key[:, y_lo:y_hi] = g["key"][:, y_lo:y_hi]
+        present[Hh - y_hi: Hh - y_lo] = g["present"][Hh - y_hi: Hh - y_lo]
+        frags += g["counters"]["fragments"]
+        outside = np.ones(Hh, dtype=bool)
+        outside[y_lo:y_hi] = False
+        assert np.isneginf(g["z"][:, outside]).all()
+    same = (z.view(np.uint64) == o["z"].view(np.uint64)) | (np.isnan(z) & np.isnan(o["z"]))
+    assert same.all(), f"{(~same).sum()} depth mismatches at {np.argwhere(~same)[:4].tolist()}"
+    assert np.array_equal(key, o["key"]) and np.array_equal(present, o["present"])
+    assert frags == o["counters"]["fragments"], (frags, o["counters"]["fragments"])
+
+
+def test_bands_and_degenerate_triangles(oracle):
+    """A triangle whose corners share one y has NaN in every sample (the split parameter is 0 / 0, mod.rs:435-441) and
+    `as` casts send them all to pixel (0, 0): in a band-sharded frame it belongs to the band that owns row 0, wherever its
+    corners lie, and to no other (found by tests/manual/fuzz_bands.py: the band test of the corners' rows used to drop it
+    from every band).  The deterministic case, then three of the fuzz's scenes, in every raster mode."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader
+
+    N = H.NONE_INDEX
+    degenerate = H.Object([[-0.5, 0.25, 0.0], [0.5, 0.25, 0.0], [0.0, 0.25, 0.0]],
+                          [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)), [[0, 0, N, 1, 1, N, 2, 2, N]])
+    big = H.Object([[-1, -1, 0.5], [1, -1, 0.5], [-1, 1, 0.5]], np.zeros((0, 3)), np.zeros((0, 3)), [[0, N, N, 1, N, N, 2, N, N]])
+    d, b = _synthetic_component(degenerate), _synthetic_component(big)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    W, Hh = 50, 70
+    for order in ((d, b), (b, d), (d,)):
+        draws = [(mc, sh) for mc in order]
+        o = SU.oracle_render(oracle, W, Hh, draws)
+        assert np.isnan(o["z"][0, 0]) == (order[0] is d)
+        for mode in (0, 1, 2):
+            _assert_bands_stitch_to(o, W, Hh, draws, [0, 16, 48, Hh], mode)
+    for seed in (5005, 5006, 5016):
+        rng = np.random.default_rng(seed)
+        n_tris = int(rng.choice([3, 17, 60, 250, 900]))
+        W = int(rng.integers(8, 500))
+        Hh = int(rng.integers(33, 400))
+        draws = _random_scene(rng, n_tris, W, Hh, spread=float(rng.choice([0.6, 1.0, 1.3, 2.5])))
+        o = SU.oracle_render(oracle, W, Hh, draws)
+        rows = (Hh + 15) // 16
+        edges = [0, 16 * (rows // 3), 16 * (2 * rows // 3), Hh]
+        edges = sorted(set(min(e, Hh) for e in edges))
+        for mode in (0, 1, 2):
+            _assert_bands_stitch_to(o, W, Hh, draws, edges, mode)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_frame_reuse_and_late_plane_requests(oracle, mode):
     """One context over several frames: the RGBA8-only resolve wipes the global raster's planes

@@ -409,7 +409,11 @@ __device__ __forceinline__ void setup_triangle(const SetupArgs& a, int k, bool f
         if (a.y_lo > 0 || a.y_hi < a.H) {
             const double ymin = fmin(fmin(vy[0], vy[1]), vy[2]), ymax = fmax(fmax(vy[0], vy[1]), vy[2]);
             const bool finite = fabs(vy[0]) < __builtin_huge_val() && fabs(vy[1]) < __builtin_huge_val() && fabs(vy[2]) < __builtin_huge_val();
-            out_of_band = finite && (ceil(ymin - kPruneMargin - 0.5) > (double)(a.y_hi - 1) || floor(ymax + kPruneMargin + 0.5) < (double)a.y_lo);
+            // (a triangle whose three corners share one y -- mod.rs:435-441: the split parameter is 0 / 0 -- has NaN in every sample's
+            // coordinates and depth, and `as` casts send them all to pixel (0, 0): it belongs to the band that owns row 0, wherever
+            // its corners are, and to no other)
+            out_of_band = finite && (ymin == ymax ? a.y_lo > 0
+                                                  : (ceil(ymin - kPruneMargin - 0.5) > (double)(a.y_hi - 1) || floor(ymax + kPruneMargin + 0.5) < (double)a.y_lo));
         }
         if (out_of_band) {
             if (a.mode & 2) a.rast[seq] = R;
