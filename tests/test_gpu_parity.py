@@ -216,6 +216,43 @@ def test_non_finite_corners(oracle):
     assert o["counters"]["culled"] == 0
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_nan_pixel_outside_the_frames_screen_box(oracle, mode):
+    """The samples of a triangle whose corners share one y land on pixel (0, 0) wherever the triangle lies: the cheap resolve
+    launches the shade blocks of the meshes' screen box only, and that box need not hold pixel (0, 0) -- which has to be
+    painted all the same, and repainted once the triangle is gone (found by tests/manual/fuzz_frames.py)."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader, ModelRendererState, clear_screen, render_mesh_component
+
+    N = H.NONE_INDEX
+    degenerate = H.Object([[0.1, 0.25, 0.0], [0.6, 0.25, 0.0], [0.3, 0.25, 0.0]],
+                          [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)), [[0, 0, N, 1, 1, N, 2, 2, N]])
+    small = H.Object([[0.5, 0.5, 0.2], [0.8, 0.5, 0.2], [0.5, 0.8, 0.2]], np.zeros((0, 3)), np.zeros((0, 3)), [[0, N, N, 1, N, N, 2, N, N]])
+    d, s_ = _synthetic_component(degenerate), _synthetic_component(small)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    W, Hh = 200, 150
+    with_nan = SU.oracle_render(oracle, W, Hh, [(d, sh), (s_, sh)])
+    without = SU.oracle_render(oracle, W, Hh, [(s_, sh)])
+    assert np.isnan(with_nan["z"][0, 0]) and np.isneginf(without["z"][0, 0])
+    assert not np.array_equal(with_nan["present"][Hh - 1, 0], without["present"][Hh - 1, 0])  # (the NaN pixel is not black)
+    st = ModelRendererState(W, Hh, raster_mode=mode)
+    try:
+        for _ in range(2):
+            clear_screen(st)
+            render_mesh_component(st, d, sh)
+            render_mesh_component(st, s_, sh)
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            SU.check_present(st, with_nan["present"], "frame with the NaN pixel")
+            clear_screen(st)
+            render_mesh_component(st, s_, sh)
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            SU.check_present(st, without["present"], "the frame after it")
+            assert st.status_flags() == 0
+    finally:
+        st.close()
+
+
 def test_offscreen_and_culled(oracle):
     """Triangles partly / fully outside the frustum: per-corner cull (mod.rs:293-312) and the
     bounds test (mod.rs:380-386); no clipping exists in the reference."""

@@ -1868,6 +1868,12 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         c->shaded_hi = c->y_hi;
         sa.trace = nullptr;
         c->last_shade_grid[0] = nothing ? 0u : sgrid.x; c->last_shade_grid[1] = nothing ? 0u : sgrid.y; c->last_shade_grid[2] = nothing ? 0u : sgrid.z;
+        sa.launch_rows = sgrid.y;
+        // Pixel (0, 0) is where every sample with NaN coordinates lands (a triangle whose corners share one y: mod.rs:435-441),
+        // whatever the screen box of the frame's meshes: a boxed launch that does not hold the frame's first block gets one more
+        // row of workgroups, the first of which takes that block (its flags say whether there is anything to paint or to
+        // repaint; the others leave at once).  A band that does not own row 0 receives no such sample.
+        if (boxed && !nothing && c->y_lo == 0 && (sa.blk_x0 != 0u || sa.blk_y0 != 0u)) sgrid.y += 1;
         static const char* shade_trace = env_diag("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
         (void)shade_trace;
         // the fused colour arithmetic (+-1 LSB) unless the caller asked for the reference's operations or for the f64 colour plane

@@ -1953,7 +1953,7 @@ struct ShadeArgs {
     uint32_t view_meshes;  // batched views: draws (meshes) per view; 1: draw-table entry v is view v's
     uint32_t blk_y0;  // first block row of the launch (band contexts, boxed launches; 0 otherwise)
     uint32_t blk_x0;  // first block column of the launch (boxed launches)
-    uint32_t launch_rows;  // batched views: block rows per view in this launch
+    uint32_t launch_rows;  // block rows (per view) of this launch; a workgroup row beyond them is the one that takes block (0, 0)
     uint32_t tiled;        // layout of wkey / depth this frame (plane_index)
     uint32_t blocks_x;  // blocks per row of the FRAME (the launch's gridDim.x may be smaller)
 };
@@ -2159,13 +2159,18 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
             t[3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
         }
     };
-    const uint32_t bx = blockIdx.x + a.blk_x0;
+    // (a boxed launch that does not start at the frame's first block has one more row of workgroups, of which the first takes
+    // block (0, 0): samples with NaN coordinates -- a triangle whose corners share one y -- land on pixel (0, 0) wherever the
+    // frame's screen box lies, and what they leave there has to be painted, and repainted when it is gone)
+    const bool extra = blockIdx.y >= a.launch_rows;
+    if (extra && blockIdx.x != 0u) return;
+    const uint32_t bx = extra ? 0u : blockIdx.x + a.blk_x0;
     const int x = (int)bx * kShadeBW + (threadIdx.x & (kShadeBW - 1));
     // (a context that owns a band of rows launches the block rows of its band only: blk_y0 is the first of them)
     // (a batch of views launches rows [blk_y0, blk_y0 + launch_rows) of every view, one view after the other)
     // (the view is the grid's z: rows x views may pass the 65 535 a grid dimension holds)
     const uint32_t view = VIEWS ? blockIdx.z : 0u;
-    const uint32_t row = a.blk_y0 + blockIdx.y;
+    const uint32_t row = extra ? 0u : a.blk_y0 + blockIdx.y;
     const uint32_t by = (VIEWS ? view * a.view_blk_rows : 0u) + row;
     const int y = (int)row * kShadeBH + (threadIdx.x / kShadeBW);
     const bool live = x < a.W && y < a.H;
