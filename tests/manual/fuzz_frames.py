@@ -43,12 +43,25 @@ def main():
         draws = []
         log = []
         exact = False
+        band = [0, H]
+        with_bands = os.environ.get("FUZZ_BANDS", "0") != "0"
 
         def check(what, mask_read):
             try:
                 o = SU.oracle_render(oracle_ffi, W, H, draws)
             except AssertionError:
                 return True  # (the reference would have panicked on a texture index: nothing to compare)
+            y_lo, y_hi = band
+            if (y_lo, y_hi) != (0, H):
+                # a band context: its rows are the whole frame's, the others read back as cleared
+                out = np.ones(H, dtype=bool)
+                out[y_lo:y_hi] = False
+                o = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in o.items()}
+                o["z"][:, out] = -np.inf
+                o["key"][:, out] = np.uint64(0xFFFFFFFFFFFFFFFF)
+                o["seq"][:, out] = -1
+                o["fb"][:, out] = np.array([0.0, 0.0, 0.0, 255.0])
+                o["present"][out[::-1]] = np.array([0, 0, 0, 255], dtype=np.uint8)
             if mask_read & _ffi.TR_OUT_Z:
                 z = st.z_buffer[..., 0]
                 same = (z.view(np.uint64) == o["z"].view(np.uint64)) | (np.isnan(z) & np.isnan(o["z"]))
@@ -80,6 +93,13 @@ def main():
                     clear_screen(st)
                     draws = []
                     log.append("clear")
+                    if with_bands and rng.random() < 0.5:
+                        rows = (H + 15) // 16
+                        a_ = int(rng.integers(0, rows))
+                        b_ = int(rng.integers(a_ + 1, rows + 1))
+                        band = [a_ * 16, min(b_ * 16, H)] if rng.random() < 0.8 else [0, H]
+                        st.set_band(band[0], band[1])
+                        log.append(f"band {band}")
                 elif op == "draw" and len(draws) < 4:
                     mc = pool[int(rng.integers(0, 3))]
                     sh = shader()
