@@ -253,6 +253,50 @@ def test_nan_pixel_outside_the_frames_screen_box(oracle, mode):
         st.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_nan_pixel_of_a_band_whose_rows_miss_the_meshes(oracle, mode):
+    """The same pixel in a band context: the band owns row 0, the meshes' screen box misses the band's rows altogether (an
+    empty launch box is not an empty launch), and afterwards a band that does not own row 0 has to read back a cleared
+    pixel (0, 0) -- both found by tests/manual/fuzz_frames.py with FUZZ_BANDS=1."""
+    from tinyrenderer_amd import _ffi
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import BuiltinShader, ModelRendererState, clear_screen, render_mesh_component
+
+    N = H.NONE_INDEX
+    degenerate = H.Object([[0.1, 0.5, 0.0], [0.6, 0.5, 0.0], [0.3, 0.5, 0.0]],
+                          [[0, 0, 0], [1, 0, 0], [0.5, 1, 0]], np.zeros((0, 3)), [[0, 0, N, 1, 1, N, 2, 2, N]])
+    small = H.Object([[0.5, 0.6, 0.2], [0.8, 0.6, 0.2], [0.5, 0.9, 0.2]], np.zeros((0, 3)), np.zeros((0, 3)), [[0, N, N, 1, N, N, 2, N, N]])
+    d, s_ = _synthetic_component(degenerate), _synthetic_component(small)
+    sh = BuiltinShader(np.eye(4), np.eye(4), (0.0, 0.0, 2.0))
+    W, Hh = 120, 160
+    o = SU.oracle_render(oracle, W, Hh, [(d, sh), (s_, sh)])
+    assert np.isnan(o["z"][0, 0])
+    black = np.array([0, 0, 0, 255], dtype=np.uint8)
+    st = ModelRendererState(W, Hh, raster_mode=mode)
+    try:
+        for _ in range(2):
+            clear_screen(st)
+            st.set_band(0, 48)                      # rows 0..47: the meshes lie above row 100
+            render_mesh_component(st, d, sh)
+            render_mesh_component(st, s_, sh)
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            want = np.broadcast_to(black, o["present"].shape).copy()
+            want[Hh - 48:] = o["present"][Hh - 48:]  # (presented rows are flipped)
+            assert not np.array_equal(want[Hh - 1, 0], black)
+            SU.check_present(st, want, "band [0, 48)")
+            clear_screen(st)
+            st.set_band(96, Hh)                      # does not own row 0: pixel (0, 0) reads back cleared
+            render_mesh_component(st, d, sh)
+            render_mesh_component(st, s_, sh)
+            st.resolve(_ffi.TR_OUT_RGBA8)
+            want = np.broadcast_to(black, o["present"].shape).copy()
+            want[: Hh - 96] = o["present"][: Hh - 96]
+            SU.check_present(st, want, "band [96, H)")
+            assert st.status_flags() == 0
+    finally:
+        st.close()
+
+
 def test_offscreen_and_culled(oracle):
     """Triangles partly / fully outside the frustum: per-corner cull (mod.rs:293-312) and the
     bounds test (mod.rs:380-386); no clipping exists in the reference."""

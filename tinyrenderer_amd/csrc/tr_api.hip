@@ -74,6 +74,7 @@ struct tr_context {
     PixBox frame_box;   // where this frame's draws can land a sample (projected mesh boxes, a margin added); tr_clear empties it
     uint32_t last_shade_grid[3] = {0, 0, 0};  // workgroups of the last shade launch (tr_get_shade_launch)
     PixBox paint_box;   // where the colour plane may differ from the background after the last shade launch
+    bool origin_maybe_painted = false;  // ... and pixel (0, 0) beside it: the last boxed launch's frame had triangles (NaN samples land there)
     bool depth_split = true;  // TR_DEPTH_SPLIT: draws that use k_small / k_mid split their triangles at the depth of the mesh box's centre
     bool split_any = false;   // a draw of this frame did
     bool plane_tiles = true;   // TR_PLANE_TILES: frames whose first draw uses k_small keep their planes in 4 x 2 tiles
@@ -1836,8 +1837,14 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             if (views && c->n_views < c->max_views) c->paint_box.add(cur);
             else c->paint_box = cur;
             boxed = true;
+            // (pixel (0, 0) -- where samples with NaN coordinates land, see below -- may hold something whenever the frame has
+            // triangles, and may have to be wiped whenever the last boxed launch's frame had: an empty box alone does not
+            // make an empty launch)
+            const bool origin = c->tri_total > 0 || c->origin_maybe_painted;
+            c->origin_maybe_painted = c->tri_total > 0;
             if (go.empty()) {
-                nothing = true;
+                if (origin) { sa.blk_x0 = 1; sa.blk_y0 = 0; sgrid.x = 1; sgrid.y = 0; sa.launch_rows = 0; }  // the workgroup of block (0, 0) only
+                else nothing = true;
             } else {
                 sa.blk_x0 = (uint32_t)(go.x0 / kShadeBW);
                 sa.blk_y0 = (uint32_t)(go.y0 / kShadeBH);
@@ -1856,6 +1863,7 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
             }
         } else {
             c->paint_box.x0 = 0; c->paint_box.y0 = 0; c->paint_box.x1 = c->W; c->paint_box.y1 = c->H;
+            c->origin_maybe_painted = false;  // (inside paint_box)
         }
         if (!boxed && !views && !shade_trace_on() && out_mask == TR_OUT_RGBA8 && (c->y_lo > 0 || c->y_hi < c->H || c->shaded_lo > 0 || c->shaded_hi < c->H)) {
             // a band context (RGBA8 only: the other planes are rewritten whole): nothing lands outside [y_lo, y_hi); the
@@ -1872,8 +1880,9 @@ static int resolve_frame(tr_context* c, uint32_t out_mask, bool colour) {
         // Pixel (0, 0) is where every sample with NaN coordinates lands (a triangle whose corners share one y: mod.rs:435-441),
         // whatever the screen box of the frame's meshes: a boxed launch that does not hold the frame's first block gets one more
         // row of workgroups, the first of which takes that block (its flags say whether there is anything to paint or to
-        // repaint; the others leave at once).  A band that does not own row 0 receives no such sample.
-        if (boxed && !nothing && c->y_lo == 0 && (sa.blk_x0 != 0u || sa.blk_y0 != 0u)) sgrid.y += 1;
+        // repaint; the others leave at once).  A band that does not own row 0 receives no such sample, but may have to wipe
+        // what an earlier frame of this context, with other rows, left there.
+        if (boxed && !nothing && (sa.blk_x0 != 0u || sa.blk_y0 != 0u)) sgrid.y += 1;
         static const char* shade_trace = env_diag("TR_SHADE_TRACE");  // debugging aid, tools/shade_trace.py
         (void)shade_trace;
         // the fused colour arithmetic (+-1 LSB) unless the caller asked for the reference's operations or for the f64 colour plane
