@@ -45,6 +45,10 @@ def main():
         exact = False
         band = [0, H]
         with_bands = os.environ.get("FUZZ_BANDS", "0") != "0"
+        # FUZZ_PEER=1: a second context on the device comes and goes between the operations -- the library sizes its raster
+        # workgroups and the slot sequence's chunks by whether the context is alone, also in the middle of a frame
+        with_peer = os.environ.get("FUZZ_PEER", "0") != "0"
+        peer = None
 
         def check(what, mask_read):
             try:
@@ -88,7 +92,7 @@ def main():
         try:
             clear_screen(st)
             for step in range(int(rng.integers(6, 20))):
-                op = rng.choice(["clear", "draw", "draw", "resolve", "resolve", "late", "exact"])
+                op = rng.choice(["clear", "draw", "draw", "resolve", "resolve", "late", "exact"] + (["peer"] if with_peer else []))
                 if op == "clear":
                     clear_screen(st)
                     draws = []
@@ -125,6 +129,13 @@ def main():
                     log.append(f"late {bit:#x}")
                     check(" > ".join(log[-8:]), bit)
                     steps += 1
+                elif op == "peer":
+                    if peer is None:
+                        peer = ModelRendererState(32, 32)
+                    else:
+                        peer.close()
+                        peer = None
+                    log.append("peer" + ("+" if peer is not None else "-"))
                 elif op == "exact":
                     exact = not exact
                     st.set_colour_exact(exact)
@@ -134,6 +145,8 @@ def main():
             print(f"FAIL seed {seed0 + k} mode {mode} {W}x{H}: {str(e)[:300]}\n     full sequence: " + " > ".join(log), flush=True)
         finally:
             st.close()
+            if peer is not None:
+                peer.close()
         if k % 10 == 9:
             print(f"{k + 1} sequences done ({steps} checks), {bad} failures", flush=True)
     print(f"fuzz_frames: {n} sequences, {steps} checks, mode {mode}, {bad} failures")
