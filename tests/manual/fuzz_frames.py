@@ -25,9 +25,15 @@ def main():
     from tinyrenderer_amd import _ffi
     from tinyrenderer_amd.model_renderer import BuiltinShader, ModelRendererState, clear_screen, render_mesh_component
 
-    bad = 0
-    steps = 0
-    for k in range(n):
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    lock = threading.Lock()
+    totals = {"bad": 0, "steps": 0, "done": 0}
+
+    def run_one(k):
+        bad = 0
+        steps = 0
         rng = np.random.default_rng(seed0 + k)
         W = int(rng.integers(16, 400))
         H = int(rng.integers(16, 300))
@@ -147,8 +153,22 @@ def main():
             st.close()
             if peer is not None:
                 peer.close()
-        if k % 10 == 9:
-            print(f"{k + 1} sequences done ({steps} checks), {bad} failures", flush=True)
+        with lock:
+            totals["bad"] += bad
+            totals["steps"] += steps
+            totals["done"] += 1
+            if totals["done"] % 10 == 0:
+                print(f"{totals['done']} sequences done ({totals['steps']} checks), {totals['bad']} failures", flush=True)
+    # FUZZ_THREADS=k: k host threads, each with a context of its own, at the same time (the library's per-device state:
+    # the count of live contexts, the static staging array, the loaders' thread-local error text)
+    n_threads = int(os.environ.get("FUZZ_THREADS", "1"))
+    if n_threads > 1:
+        with ThreadPoolExecutor(n_threads) as ex:
+            list(ex.map(run_one, range(n)))
+    else:
+        for k in range(n):
+            run_one(k)
+    bad, steps = totals["bad"], totals["steps"]
     print(f"fuzz_frames: {n} sequences, {steps} checks, mode {mode}, {bad} failures")
     return 1 if bad else 0
 
