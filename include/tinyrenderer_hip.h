@@ -252,8 +252,9 @@ int tr_render_views_multi(tr_context* ctx, int n_meshes, const tr_mesh* const* m
  * The bands of a frame stack to the whole frame bit for bit, including the one sample that does not land where its
  * triangle lies: a triangle whose corners share one y on the screen has NaN in every sample (mod.rs:435-441) and lands
  * on pixel (0, 0), so it is drawn by the band that owns row 0 and by no other.  One exception: in a draw of >= 65 536
- * triangles whole clusters of 64 are dropped by their boxes before any triangle is looked at, and such a triangle inside
- * a dropped cluster does not reach pixel (0, 0). */
+ * triangles whole clusters of 64 are dropped by their boxes before any triangle is looked at; a cluster that holds a
+ * triangle of three identical positions (degenerate under every view) is never dropped, but a triangle that only
+ * PROJECTS onto one screen row under the frame's matrices, inside a dropped cluster, does not reach pixel (0, 0). */
 int tr_set_band(tr_context* ctx, int y_lo, int y_hi);
 int tr_set_raster_mode(tr_context* ctx, int mode);
 

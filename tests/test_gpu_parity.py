@@ -461,6 +461,30 @@ def test_bands_and_degenerate_triangles(oracle):
             _assert_bands_stitch_to(o, W, Hh, draws, edges, mode)
 
 
+def test_bands_of_a_large_draw_with_a_one_point_triangle(oracle):
+    """Draws of >= 65 536 triangles drop whole clusters of 64 by their boxes before a band context looks at a triangle
+    (k_cull_clusters).  A triangle of three identical positions is degenerate under every view -- its samples are NaN and
+    land on pixel (0, 0), far from its cluster's box --, so its cluster is never dropped (k_mesh_bounds) and the band that owns
+    row 0 gets the triangle."""
+    from tinyrenderer_amd import helpers as H
+    from tinyrenderer_amd.model_renderer import MeshComponent
+
+    W, Hh = 640, 480
+    head = SU.component("head")
+    fine = scenes.subdivide(head.mesh, 3)
+    tri = fine.triangles.copy()
+    k = int(np.argmax(fine.vertices[tri[:, 0], 1]))  # a triangle at the top of the head: rows far from row 0
+    tri[k, 3] = tri[k, 0]
+    tri[k, 6] = tri[k, 0]
+    mc = MeshComponent(H.Object(fine.vertices, fine.tex_vertices, fine.normals, tri, fine.name), head.texture, head.normal_map)
+    mc.transform.set_rotation((0.025, 0.0, 0.0))
+    draws = [(mc, scenes.shader_for(mc, W, Hh))]
+    o = SU.oracle_render(oracle, W, Hh, draws)
+    assert np.isnan(o["z"][0, 0]), "the one-point triangle's samples should own pixel (0, 0)"
+    for mode in (0, 1):
+        _assert_bands_stitch_to(o, W, Hh, draws, [0, 160, 320, Hh], mode)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_frame_reuse_and_late_plane_requests(oracle, mode):
     """One context over several frames: the RGBA8-only resolve wipes the global raster's planes

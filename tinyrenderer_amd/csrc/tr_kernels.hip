@@ -619,7 +619,16 @@ __global__ __launch_bounds__(256) void k_mesh_bounds(const uint32_t* __restrict_
     double lo[3] = {__builtin_huge_val(), __builtin_huge_val(), __builtin_huge_val()};
     double hi[3] = {-__builtin_huge_val(), -__builtin_huge_val(), -__builtin_huge_val()};
     bool bad = false;
-    for (uint32_t t = t0; t < t1; ++t)
+    for (uint32_t t = t0; t < t1; ++t) {
+        // (a triangle of three identical positions is degenerate under every view: all of its samples are NaN and land on pixel
+        // (0, 0), far from the cluster's box -- such a cluster is never culled, and setup_triangle gives the triangle to the band
+        // that owns row 0.  Triangles that only PROJECT onto one screen row are view-dependent and stay the documented exception.)
+        const uint32_t va = idx[9 * (size_t)t], vb = idx[9 * (size_t)t + 3], vc = idx[9 * (size_t)t + 6];
+        bool same = true;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            same = same && pos[3 * (size_t)va + d] == pos[3 * (size_t)vb + d] && pos[3 * (size_t)vb + d] == pos[3 * (size_t)vc + d];
+        bad = bad || same;
         for (int cnr = 0; cnr < 3; ++cnr) {
             const uint32_t v = idx[9 * (size_t)t + 3 * cnr];
 #pragma unroll
@@ -630,8 +639,9 @@ __global__ __launch_bounds__(256) void k_mesh_bounds(const uint32_t* __restrict_
                 hi[d] = fmax(hi[d], p);
             }
         }
+    }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {  // (a non-finite position: a box nothing is culled against)
+    for (int d = 0; d < 3; ++d) {  // (a non-finite position, or a triangle of one point: a box nothing is culled against)
         bounds[6 * (size_t)c + d] = bad ? __builtin_nan("") : lo[d];
         bounds[6 * (size_t)c + 3 + d] = bad ? __builtin_nan("") : hi[d];
     }
